@@ -1,0 +1,133 @@
+"""The CPU oracle (oracle/seunet_oracle.py) against the fixtures generated from the
+real reference by oracle/make_golden.py.  Runs everywhere (no GPU, no /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import seunet_oracle as orc
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_registry_matches_survey_counts():
+    reg = orc.parameter_registry(2, 1, 1)
+    assert len(reg) == 117
+    assert sum(int(np.prod(s)) for _, s in reg) == 1_520_314
+    m = orc.OracleSEUNet(2, 1)
+    assert [k for k, _ in reg] == list(m.state_dict().keys())
+    assert all(tuple(v.shape) == s for (k, s), v in zip(reg, m.state_dict().values()))
+    assert len(list(m.buffers())) == 0
+
+
+@pytest.mark.parametrize("tag,inch", [("fwd32_in2", 2), ("fwd32_in1", 1)])
+def test_eval_forward_32(golden_dir, tag, inch):
+    g = _load(golden_dir, tag + ".npz")
+    m = orc.build_oracle(inch, 1, 1, seed=0)
+    x = orc.synthetic_batch(2, (32, 32, 32), inch, seed=1)["image"]
+    with torch.no_grad():
+        p0, p1 = m(x)
+    np.testing.assert_allclose(p0.numpy(), g["pred0"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(p1.numpy(), g["pred1"], atol=1e-6, rtol=0)
+
+
+def test_eval_forward_64_config1(golden_dir):
+    """BASELINE.json configs[0]: fp32 1x64^3 CPU forward."""
+    g = _load(golden_dir, "fwd64_in2.npz")
+    m = orc.build_oracle(2, 1, 1, seed=0)
+    x = orc.synthetic_batch(1, (64, 64, 64), 2, seed=2)["image"]
+    with torch.no_grad():
+        p0, p1 = m(x)
+    np.testing.assert_allclose(p0[0, 0, ::4, ::4, ::4].numpy(), g["pred0_s"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(p1[0, 0, ::4, ::4, ::4].numpy(), g["pred1_s"], atol=1e-6, rtol=0)
+    assert abs(float(p0.double().sum()) - float(g["pred0_sum"])) < 1e-2
+    assert abs(float(p1.double().abs().sum()) - float(g["pred1_abs"])) < 1e-2
+
+
+@pytest.mark.parametrize("stage", [1, 3])
+def test_backward_32(golden_dir, stage):
+    g = _load(golden_dir, f"bwd32_stage{stage}.npz")
+    m = orc.build_oracle(2, 1, 1, seed=0)
+    b = orc.synthetic_batch(2, (32, 32, 32), 2, seed=3)
+    pe, pd = m(b["image"])
+    loss = orc.stage_loss(stage, pe, pd, b["label"], b["weight"], b["skel"])
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    for name, p in m.named_parameters():
+        if name + "|none" in g.files:
+            assert p.grad is None, name                     # dead dc62
+            continue
+        gn = float(g[name + "|norm"])
+        assert abs(float(p.grad.double().norm()) - gn) <= 1e-5 * max(gn, 1e-6) + 1e-9, name
+        np.testing.assert_allclose(p.grad.reshape(-1)[:8].numpy(), g[name + "|head"],
+                                   rtol=1e-4, atol=1e-8, err_msg=name)
+
+
+def test_train_mode_droplayer(golden_dir):
+    """DropLayer RNG order and batch-coupled scale."""
+    g = _load(golden_dir, "fwd32_train.npz")
+    m = orc.build_oracle(2, 1, 1, seed=0, train=True)
+    x = orc.synthetic_batch(2, (32, 32, 32), 2, seed=4)["image"]
+    torch.manual_seed(123)
+    with torch.no_grad():
+        p0, p1 = m(x)
+    np.testing.assert_allclose(p0.numpy(), g["pred0"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(p1.numpy(), g["pred1"], atol=1e-6, rtol=0)
+
+
+def test_losses_known_answers(golden_dir):
+    g = _load(golden_dir, "loss_known.npz")
+    # values quoted in SURVEY.md section 8(c)
+    assert abs(float(g["dice_loss"]) - 0.81824607) < 1e-6
+    assert abs(float(g["general_union_loss_lib"]) - 0.65585136) < 1e-6
+    assert abs(float(g["atr_loss"]) - 0.67657852) < 1e-6
+    gen = torch.Generator().manual_seed(1234)
+    p = torch.rand(2, 1, 16, 16, 16, generator=gen)
+    t = (torch.rand(2, 1, 16, 16, 16, generator=gen) > 0.9).float()
+    w = 1 + torch.rand(2, 1, 16, 16, 16, generator=gen)
+    s = t * (torch.rand(2, 1, 16, 16, 16, generator=gen) > 0.5).float()
+    for name, fn, args in (("dice_loss", orc.dice_loss, (t,)),
+                           ("general_union_loss_lib", orc.general_union_loss_lib, (t, w)),
+                           ("atr_loss", orc.atr_loss, (t, s, w))):
+        pp = p.clone().requires_grad_(True)
+        l = fn(pp, *args)
+        l.backward()
+        assert abs(float(l) - float(g[name])) < 1e-6
+        np.testing.assert_allclose(pp.grad.numpy(), g[name + "|grad"], rtol=1e-5, atol=1e-10)
+
+
+def test_window_starts(golden_dir):
+    g = _load(golden_dir, "window_starts.npz")
+    for k in g.files:
+        assert orc.window_starts(int(k)) == list(g[k]), k
+    assert len(orc.window_starts(512)) == 7                   # 343 windows for 512^3
+    with pytest.raises(ValueError):
+        orc.window_starts(100)
+
+
+def test_sliding_window_equals_bruteforce():
+    """Assembled volume == per-voxel mean over the window outputs covering it."""
+    class Tiny(torch.nn.Module):
+        def forward(self, x):
+            y = x[:, :1] * 3.0 - x[:, 1:2] + x[:, :1].mean()
+            return y, y
+    x = torch.rand(1, 2, 24, 20, 16)
+    out = orc.sliding_window_predict(Tiny(), x, cube=16, step=8)
+    acc = np.zeros((24, 20, 16)); cnt = np.zeros((24, 20, 16))
+    for a in orc.window_starts(24, 16, 8):
+        for b in orc.window_starts(20, 16, 8):
+            for c in orc.window_starts(16, 16, 8):
+                w = x[:, :, a:a + 16, b:b + 16, c:c + 16]
+                acc[a:a + 16, b:b + 16, c:c + 16] += torch.sigmoid(Tiny()(w)[1])[0, 0].numpy()
+                cnt[a:a + 16, b:b + 16, c:c + 16] += 1
+    np.testing.assert_allclose(out, acc / cnt, atol=1e-12)
+
+
+def test_two_channel():
+    hu = np.array([-2000.0, -1024, -1000, 0, 500, 1024, 3000])
+    c0, c1 = orc.two_channel(hu)
+    np.testing.assert_allclose(c0, [0, 0, 24 / 2048, 0.5, 1524 / 2048, 1, 1])
+    np.testing.assert_allclose(c1, [0, 0, 0, 1000 / 1500, 1, 1, 1])
