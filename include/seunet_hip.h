@@ -1,0 +1,153 @@
+/* seunet_hip.h -- C ABI of libseunet_hip.so: the MI355X (gfx950) SE-UNet hot path.
+ *
+ * The reference (Beryl2000/SE-UNet-AirSeg) has no native / FFI layer: its boundary for this path is
+ * the Python nn.Module surface of SE_UNet.py plus three loss functions in train.py.
+ * This header is the C boundary a binding for that surface talks to; every entry point names the
+ * reference code it replaces.  Conventions:
+ *   - plain C, no torch types: raw device pointers, explicit shapes, a dtype enum, a hipStream_t;
+ *   - every function returns 0 on success, non-zero on error (message: seunet_last_error(), thread
+ *     local); nothing throws across the ABI, nothing allocates/frees caller memory, nothing
+ *     synchronises the device; workspaces are caller-owned;
+ *   - re-entrant: no global mutable state, everything is parameterised by (pointers, stream);
+ *   - activations inside the library are channels-last [N][D][H][W][C], C a multiple of 8, f32 or
+ *     bf16 (SEUNET_F32 / SEUNET_BF16); parameters, logits, losses and gradients of parameters are
+ *     f32 in the PyTorch layouts of the reference's state_dict.
+ */
+#ifndef SEUNET_HIP_H
+#define SEUNET_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef SEUNET_F32
+#define SEUNET_F32 0
+#define SEUNET_BF16 1
+#endif
+#define SEUNET_CONV_MFMA 0   /* implicit-GEMM matrix-core kernels (default)                  */
+#define SEUNET_CONV_NAIVE 1  /* one-thread-per-output HIP kernels (device-side cross-check)  */
+
+typedef void* seunet_stream_t; /* a hipStream_t */
+typedef struct seunet_dims { int n, d, h, w; } seunet_dims;
+
+int seunet_version(void);
+const char* seunet_last_error(void);
+
+/* ---- layout: reference tensors are NCDHW f32 (SE_UNet.py:181 "x: 1 2 128 128 128") ---------------- */
+int seunet_pack_cl(int dtype, const float* in_ncdhw, int c, void* out_cl, int c_pad, seunet_dims dims, seunet_stream_t s);
+int seunet_unpack_cl(int dtype, const void* in_cl, int c, float* out_ncdhw, seunet_dims dims, seunet_stream_t s);
+
+/* ---- nn.Conv3d 3x3x3 (dilation 1|2, padding = dilation) and 1x1x1; SE_UNet.py:15,42,57 -------------
+ * src/dst lists realise torch.cat (SE_UNet.py:186,195,204,212,216,218,222,224,228) and its backward.
+ * weights: SEUNET_CONV_MFMA -> buffer produced by seunet_conv_pack_weights; SEUNET_CONV_NAIVE -> the
+ * PyTorch (Cout,Cin,k,k,k) f32 tensor.  transpose_flip=1 selects the data-gradient operator.
+ * stats_partial (optional): [n][seunet_conv_stats_slots][cout][2] f32 partial (sum, sum of squares)
+ * for the following InstanceNorm3d (SE_UNet.py:17,43,59). */
+size_t seunet_conv_wpack_bytes(int dtype, int taps, int cin, int cout);
+int seunet_conv_pack_weights(int dtype, const float* w, int taps, int cin, int cout, int transpose_flip, void* wpack, seunet_stream_t s);
+int seunet_conv_stats_slots(int impl, seunet_dims dims);
+int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
+                      int cin, const void* weights, int transpose_flip, const float* bias, int ndst, void* const* dst,
+                      const int* dst_c, const int* dst_accumulate, float* stats_partial, seunet_dims dims, seunet_stream_t s);
+size_t seunet_conv3d_wgrad_workspace_bytes(int taps, int cin, int cout);
+int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
+                        int cin, const void* dy, int cout, float* dw, void* workspace, size_t workspace_bytes,
+                        seunet_dims dims, seunet_stream_t s);
+
+/* ---- InstanceNorm3d statistics (eps, biased variance; SE_UNet.py:17,43,59) -------------------------- */
+int seunet_epilogue_slots(seunet_dims dims);
+int seunet_channel_stats(int dtype, const void* t, int c, float* partial, seunet_dims dims, seunet_stream_t s);
+/* mode 0: (mean, rstd) ; mode 1: (sum/count, sumsq/count) */
+int seunet_stats_finalize(const float* partial, int slots, int c, int n, long long count, float eps, int mode,
+                          float* out_a, float* out_b, seunet_stream_t s);
+
+/* ---- gated block epilogue: IN -> LeakyReLU -> gate(s) -> e, side = conv1x1(e); SE_UNet.py:24-35,68-82 --
+ * w_se2 == NULL selects the one-gate SSEConv.  side_out: f32 [n][vox][2] (optional).  level_map: f32
+ * [n][vox] head pre-activation map (optional): += head_w[k]*drop[n][k]*side[k] (SE_UNet.py:232-233). */
+int seunet_gate_epilogue_fwd(int dtype, const void* raw, const float* mean, const float* rstd, int c, const float* w_se,
+                             const float* w_se2, const float* w_side, const float* b_side, float slope, void* e_out,
+                             float* side_out, float* level_map, int level_accumulate, const float* head_w,
+                             const float* drop, int drop_stride, seunet_dims dims, seunet_stream_t s);
+/* backward pass A.  dxhat_out may alias g_e.  stat_partial: [n][slots][c][2]; pgrad_partial:
+ * [n*slots][4c+4] = dw_se | dw_se2 | dw_side[2][c] | db_side[2] | dhead_w[2]. */
+int seunet_gate_epilogue_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int c, const float* w_se,
+                             const float* w_se2, const float* w_side, const float* b_side, float slope, const void* g_e,
+                             const float* g_side, const float* g_level, const float* head_w, const float* drop,
+                             int drop_stride, void* dxhat_out, float* stat_partial, float* pgrad_partial,
+                             seunet_dims dims, seunet_stream_t s);
+int seunet_pgrad_reduce(const float* pgrad_partial, int records, int c, float* dw_se, float* dw_se2, float* dw_side,
+                        float* db_side, float* dhead_w, seunet_stream_t s);
+/* InstanceNorm backward pass B, in place: dx <- rstd*(dx - m1 - xhat*m2) */
+int seunet_in_bwd(int dtype, void* dx, const void* raw, const float* mean, const float* rstd, const float* m1,
+                  const float* m2, int c, seunet_dims dims, seunet_stream_t s);
+
+/* ---- aggregation block: conv1x1 -> IN -> LeakyReLU (+ x-branch); SE_UNet.py:45-49,187,196,205 -------- */
+int seunet_cat_epilogue_fwd(int dtype, const void* raw, const float* mean, const float* rstd, const void* raw2,
+                            const float* mean2, const float* rstd2, int c, float slope, void* out, seunet_dims dims,
+                            seunet_stream_t s);
+int seunet_cat_epilogue_bwd(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                            const void* raw2, const float* mean2, const float* rstd2, int c, float slope,
+                            void* dxhat_out, void* dxhat2_out, float* stat_partial, float* stat_partial2,
+                            seunet_dims dims, seunet_stream_t s);
+
+/* ---- nn.MaxPool3d(2,2) SE_UNet.py:131-133 ; nn.Upsample(x2 trilinear align_corners) :136-138 ---------- */
+int seunet_maxpool_fwd(int dtype, const void* in, int c, void* out, seunet_dims in_dims, seunet_stream_t s);
+int seunet_maxpool_bwd(int dtype, const void* in, const void* g_out, int c, void* g_in, int accumulate,
+                       seunet_dims in_dims, seunet_stream_t s);
+int seunet_upsample2_fwd(int dtype, const void* in, int c, void* out, seunet_dims in_dims, seunet_stream_t s);
+int seunet_upsample2_bwd(int dtype, const void* g_out, int c, void* g_in, int accumulate, seunet_dims in_dims,
+                         seunet_stream_t s);
+/* side map [n][vox_low][c] f32 -> NCDHW f32 channels [c_off, c_off+c) of an (n, c_total, ...) tensor */
+int seunet_side_upsample(const float* side, int c, int scale, float* out_ncdhw, int c_total, int c_off,
+                         seunet_dims low_dims, seunet_stream_t s);
+
+/* ---- heads: dc0_0 / dc0_1 over the DropLayer-scaled side stack; SE_UNet.py:150-153,232-233 ------------ */
+int seunet_head_fwd(const float* const* level_maps, int nlevels, const float* bias, float* pred, seunet_dims dims,
+                    seunet_stream_t s);
+size_t seunet_head_bwd_tmp_floats(seunet_dims dims);
+int seunet_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, float* tmp, float* g_bias,
+                    seunet_dims dims, seunet_stream_t s);
+
+/* ---- losses: dice_loss / general_union_loss_lib / atr_loss; train.py:51-76 ------------------------------
+ * sums[7] (f64, device): see csrc/loss.hip.  The caller forms the loss from the sums (and all-reduces
+ * them first under data parallelism), then calls seunet_loss_grad; the upstream gradient is
+ * g_scale * (g_scale_dev ? *g_scale_dev : 1) so it can stay on the device. */
+int seunet_loss_partial_floats(void);
+int seunet_loss_sums(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
+                     long long n, float* partial, double* sums, seunet_stream_t s);
+int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
+                     long long n, const double* sums, float c_dice, float c_gul, float c_atr, float g_scale,
+                     const float* g_scale_dev, float* g_pred, seunet_stream_t s);
+
+/* ---- whole network: SE_UNet.forward (SE_UNet.py:181-238) and its backward ------------------------------- */
+typedef struct seunet_net_desc {
+  int batch, in_channel, n_classes;
+  int d, h, w;          /* multiples of 8 */
+  int width_mult;       /* 1 = reference widths 8/16/32/64 (SE_UNet.py:108-148) */
+  int dtype;            /* activation storage: SEUNET_F32 | SEUNET_BF16 */
+  int conv_impl;        /* SEUNET_CONV_MFMA | SEUNET_CONV_NAIVE */
+  float negative_slope; /* 0.01 (nn.LeakyReLU default, SE_UNet.py:18) */
+  float eps;            /* 1e-5 (nn.InstanceNorm3d default) */
+} seunet_net_desc;
+
+int seunet_net_param_count(const seunet_net_desc* desc);
+/* name: state_dict key; shape: up to 5 extents (PyTorch layout), ndim 1 or 5 */
+int seunet_net_param_info(const seunet_net_desc* desc, int index, char* name, int name_cap, int* shape5, int* ndim);
+size_t seunet_net_workspace_bytes(const seunet_net_desc* desc);
+/* params: seunet_net_param_count device pointers in registry order.  x: NCDHW f32.  drop1/drop2: DropLayer
+ * scale tensors [batch][24] / [batch][12] (NULL = eval mode identity).  pred0/pred1: [batch][1][d][h][w] f32 logits.
+ * The workspace keeps everything the backward pass needs; pass the same buffer to seunet_net_backward. */
+int seunet_net_forward(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
+                       const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
+                       seunet_stream_t s);
+/* grads: device pointers in registry order, each overwritten (NULL = skip).  The dead block dc62
+ * (SE_UNet.py:148,230) receives no gradient: its entry is never written. */
+int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
+                        const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
+                        void* workspace, size_t workspace_bytes, seunet_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEUNET_HIP_H */

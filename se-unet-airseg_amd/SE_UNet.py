@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's ``SE_UNet.py`` module surface, backed by the gfx950 HIP
+library (``libseunet_hip.so``) through its C ABI.
+
+Same constructor, attribute names, ``state_dict`` (117 tensors), ``forward(x) ->
+(pred0, pred1)`` logits contract and ``get_model()`` as the reference (SE_UNet.py:99-153,181-242),
+so ``train.py`` / ``prediction.py`` style callers work unchanged:
+
+    model = SE_UNet(in_channel=2, n_classes=1).cuda()
+    pred_en, pred_de = model(data)              # HIP kernels, differentiable
+    loss = dice_loss(torch.sigmoid(pred_de), label) + dice_loss(torch.sigmoid(pred_en), label)
+    loss.backward(); optimizer.step()
+
+The whole forward (and the whole backward) is ONE call into the library
+(``seunet_net_forward`` / ``seunet_net_backward``): the graph walk, workspace layout and all kernel
+launches are native.  There is no PyTorch or CPU fallback: a CPU tensor or a missing ``.so`` raises.
+
+Extras over the reference, all defaulting to its behaviour: ``width_mult``,
+``negative_slope`` (D1), ``act_dtype`` ('bf16' performance mode / 'fp32' 1e-3-parity mode) and a
+device-agnostic ``DropLayer`` with the reference's CPU-generator RNG order (Q6).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+config = {}   # reference SE_UNet.py:7
+
+
+def _default_dtype() -> str:
+    return os.environ.get("SEUNET_DTYPE", "bf16")
+
+
+def _default_conv_impl() -> int:
+    return _lib.CONV_NAIVE if os.environ.get("SEUNET_CONV_IMPL", "mfma").lower() == "naive" else _lib.CONV_MFMA
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers with the reference's attribute names (SE_UNet.py:9-82)
+# ----------------------------------------------------------------------------------------------
+class SSEConv(nn.Module):
+    """3x3x3 conv -> InstanceNorm -> LeakyReLU -> one spatial gate; side conv C->2 (SE_UNet.py:9-35)."""
+    n_gates = 1
+
+    def __init__(self, in_channel=1, out_channel1=1, out_channel2=2, stride=1, kernel_size=3,
+                 padding=1, dilation=1, down_sample=1, bias=True):
+        super().__init__()
+        if stride != 1 or kernel_size != 3 or padding != 1 or out_channel2 != 2 or not bias:
+            raise NotImplementedError("HIP path implements the configuration SE_UNet uses: k=3, stride 1, "
+                                      "padding=dilation, 2 side channels, bias")
+        self.in_channel, self.out_channel = in_channel, out_channel1
+        self.dilation, self.down_sample = dilation, down_sample
+        self.conv1 = nn.Conv3d(in_channel, out_channel1, 3, padding=dilation, dilation=dilation, bias=True)
+        self.conv2 = nn.Conv3d(out_channel1, 2, 1, bias=True)
+        self.conv_se = nn.Conv3d(out_channel1, 1, 1, bias=False)
+        if self.n_gates == 2:
+            self.conv_se2 = nn.Conv3d(out_channel1, 1, 1, bias=False)
+
+    def forward(self, x):
+        from .ops import gated_block_forward
+        return gated_block_forward(self, x)
+
+
+class SSEConv2(SSEConv):
+    """As SSEConv with two sequential gates (SE_UNet.py:51-82)."""
+    n_gates = 2
+
+
+class CATConv(nn.Module):
+    """1x1x1 conv (no bias) -> InstanceNorm -> LeakyReLU (SE_UNet.py:37-49)."""
+
+    def __init__(self, in_channel=1, out_channel1=1):
+        super().__init__()
+        self.in_channel, self.out_channel = in_channel, out_channel1
+        self.conv1 = nn.Conv3d(in_channel, out_channel1, 1, bias=False)
+
+    def forward(self, x):
+        from .ops import cat_block_forward
+        return cat_block_forward(self, x)
+
+
+class DropLayer(nn.Module):
+    """Per-(sample, channel) keep mask with the batch-coupled rescale of SE_UNet.py:84-97.
+
+    ``scale(batch)`` draws ``torch.rand(B, C, 1, 1, 1)`` from the CPU generator exactly like the
+    reference (which then hard-codes ``.cuda()``); the scale tensor is applied inside the fused head
+    kernel, so this module never touches the big activation."""
+
+    def __init__(self, channel_num=1, thr=0.3):
+        super().__init__()
+        self.channel_num, self.threshold = channel_num, thr
+
+    def scale(self, batch: int) -> torch.Tensor:
+        r = torch.rand(batch, self.channel_num, 1, 1, 1)
+        keep = (r >= self.threshold).to(torch.float32)
+        return keep * self.channel_num / (keep.sum() + 0.01)
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        return x * self.scale(x.shape[0]).to(x.device, x.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# whole-network autograd function
+# ----------------------------------------------------------------------------------------------
+def make_desc(batch, in_channel, n_classes, d, h, w, width_mult, dtype_code, conv_impl, slope, eps=1e-5):
+    return _lib.NetDesc(batch, in_channel, n_classes, d, h, w, width_mult, dtype_code, conv_impl, slope, eps)
+
+
+def registry(desc: _lib.NetDesc) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(name, shape) list as the native library lays the parameters out."""
+    lib = _lib.load()
+    out = []
+    n = lib.seunet_net_param_count(C.byref(desc))
+    buf = C.create_string_buffer(64)
+    shape = (C.c_int * 5)()
+    nd = C.c_int()
+    for i in range(n):
+        _lib.check(lib.seunet_net_param_info(C.byref(desc), i, buf, 64, shape, C.byref(nd)), "param_info")
+        out.append((buf.value.decode(), tuple(shape[k] for k in range(nd.value))))
+    return out
+
+
+class _SEUNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop1, drop2, meta, *params):
+        lib = _lib.load()
+        b, _, d, h, w = x.shape
+        desc = make_desc(b, meta["in_channel"], meta["n_classes"], d, h, w, meta["width_mult"],
+                         meta["dtype"], meta["conv_impl"], meta["negative_slope"])
+        ws_bytes = lib.seunet_net_workspace_bytes(C.byref(desc))
+        if ws_bytes == 0:
+            raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        pred0 = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
+        pred1 = torch.empty_like(pred0)
+        plist = [p.detach().contiguous() for p in params]
+        parr = _lib.ptr_array(plist)
+        _lib.check(lib.seunet_net_forward(C.byref(desc), parr, x.data_ptr(), _lib.ptr(drop1), _lib.ptr(drop2),
+                                          pred0.data_ptr(), pred1.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          _lib.stream_ptr()), "net_forward")
+        ctx.desc, ctx.ws, ctx.ws_bytes = desc, ws, ws_bytes
+        ctx.plist, ctx.drop = plist, (drop1, drop2)
+        ctx.dead = meta["dead"]
+        return pred0, pred1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        lib = _lib.load()
+        dev = ctx.ws.device
+        shape = (ctx.desc.batch, 1, ctx.desc.d, ctx.desc.h, ctx.desc.w)
+        g0 = torch.zeros(shape, dtype=torch.float32, device=dev) if g0 is None else g0.contiguous().float()
+        g1 = torch.zeros(shape, dtype=torch.float32, device=dev) if g1 is None else g1.contiguous().float()
+        # all parameter gradients live in ONE flat buffer (one RCCL all-reduce under data parallelism)
+        sizes = [p.numel() for p in ctx.plist]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for p, n, dead in zip(ctx.plist, sizes, ctx.dead):
+            grads.append(None if dead else flat[off:off + n].view_as(p))
+            off += n
+        garr = _lib.ptr_array(grads)
+        parr = _lib.ptr_array(ctx.plist)
+        _lib.check(lib.seunet_net_backward(C.byref(ctx.desc), parr, g0.data_ptr(), g1.data_ptr(),
+                                           _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
+                                           ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr()), "net_backward")
+        ctx.ws = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class SE_UNet(nn.Module):
+    """Drop-in for the reference ``SE_UNet`` (SE_UNet.py:99-238) on MI355X."""
+
+    def __init__(self, in_channel=1, n_classes=1, width_mult=1, negative_slope=0.01,
+                 act_dtype: Optional[str] = None, conv_impl: Optional[int] = None):
+        super().__init__()
+        self.in_channel, self.n_classes = in_channel, n_classes
+        self.width_mult, self.negative_slope = width_mult, negative_slope
+        self.act_dtype = act_dtype or _default_dtype()
+        self.conv_impl = _default_conv_impl() if conv_impl is None else conv_impl
+        self.batchnorm, self.bias, self.out_channel2, self.sigmoid_output = False, True, 2, 0
+        m = width_mult
+        # registration order == reference SE_UNet.py:108-153 (state_dict / parameters() order)
+        self.ec1 = SSEConv(in_channel, 8 * m)
+        self.ec2 = SSEConv(8 * m, 16 * m)
+        self.ec3 = SSEConv(16 * m, 32 * m, dilation=2)
+        self.ec33 = CATConv(56 * m, 32 * m)
+        self.x33 = CATConv(in_channel, 32 * m)
+        self.ec4 = SSEConv2(32 * m, 32 * m, down_sample=2)
+        self.ec5 = SSEConv2(32 * m, 32 * m, dilation=2, down_sample=2)
+        self.ec6 = SSEConv2(32 * m, 64 * m, dilation=2, down_sample=2)
+        self.ec63 = CATConv(128 * m, 64 * m)
+        self.x63 = CATConv(in_channel, 64 * m)
+        self.ec7 = SSEConv2(64 * m, 64 * m, down_sample=4)
+        self.ec8 = SSEConv2(64 * m, 64 * m, dilation=2, down_sample=4)
+        self.ec9 = SSEConv2(64 * m, 64 * m, dilation=2, down_sample=4)
+        self.ec93 = CATConv(192 * m, 64 * m)
+        self.x93 = CATConv(in_channel, 64 * m)
+        self.ec10 = SSEConv2(64 * m, 64 * m, down_sample=8)
+        self.ec11 = SSEConv2(64 * m, 64 * m, down_sample=8)
+        self.ec12 = SSEConv2(64 * m, 64 * m, down_sample=8)
+        self.ec123 = CATConv(192 * m, 64 * m)
+        self.dc1 = SSEConv2(128 * m, 64 * m, down_sample=4)
+        self.dc2 = SSEConv2(64 * m, 64 * m, down_sample=4)
+        self.dc22 = CATConv(128 * m, 64 * m)
+        self.dc3 = SSEConv2(128 * m, 64 * m, down_sample=2)
+        self.dc4 = SSEConv2(64 * m, 32 * m, down_sample=2)
+        self.dc42 = CATConv(96 * m, 32 * m)
+        self.dc5 = SSEConv(64 * m, 32 * m, down_sample=1)
+        self.dc6 = SSEConv(32 * m, 16 * m, down_sample=1)
+        self.dc62 = CATConv(48 * m, 16 * m)     # dead in forward (SE_UNet.py:230); kept for state_dict
+        self.dc0_0 = nn.Conv3d(24, n_classes, 1, bias=True)
+        self.dc0_1 = nn.Conv3d(12, n_classes, 1, bias=True)
+        self.dropout1 = DropLayer(channel_num=24, thr=0.3)
+        self.dropout2 = DropLayer(channel_num=12, thr=0.3)
+        self._names = [n for n, _ in self.named_parameters()]
+        self._dead = [n.startswith("dc62.") for n in self._names]
+        self._registry_checked = False
+
+    def _check_registry(self, desc):
+        if self._registry_checked:
+            return
+        native = registry(desc)
+        mine = [(n, tuple(p.shape)) for n, p in self.named_parameters()]
+        if native != mine:
+            raise RuntimeError("parameter registry of libseunet_hip differs from the nn.Module's state_dict")
+        self._registry_checked = True
+
+    def forward(self, x, drop_scales: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """x: (B, in_channel, D, H, W) float, D/H/W multiples of 8 -> (pred0, pred1) logits.
+        ``drop_scales`` optionally injects the two DropLayer scale tensors (B,24,1,1,1)/(B,12,1,1,1)."""
+        if not x.is_cuda:
+            raise RuntimeError("SE_UNet (HIP path) needs a tensor on an MI355X device; there is no CPU fallback "
+                               "(the CPU oracle lives in oracle/seunet_oracle.py and is test infrastructure).")
+        if x.dim() != 5 or x.shape[1] != self.in_channel:
+            raise ValueError(f"expected input (B,{self.in_channel},D,H,W), got {tuple(x.shape)}")
+        x = x.contiguous().float()          # callers pass strided views
+        b = x.shape[0]
+        if drop_scales is not None:
+            d1, d2 = drop_scales
+        elif self.training:                 # RNG order: dropout1 then dropout2 (SE_UNet.py:232-233)
+            d1, d2 = self.dropout1.scale(b), self.dropout2.scale(b)
+        else:
+            d1 = d2 = None
+        if d1 is not None:
+            d1 = d1.reshape(b, 24).to(x.device, torch.float32).contiguous()
+            d2 = d2.reshape(b, 12).to(x.device, torch.float32).contiguous()
+        meta = {"in_channel": self.in_channel, "n_classes": self.n_classes, "width_mult": self.width_mult,
+                "dtype": _lib.dtype_code(self.act_dtype), "conv_impl": self.conv_impl,
+                "negative_slope": float(self.negative_slope), "dead": self._dead}
+        if not self._registry_checked:
+            self._check_registry(make_desc(b, self.in_channel, self.n_classes, x.shape[2], x.shape[3], x.shape[4],
+                                           self.width_mult, meta["dtype"], self.conv_impl, self.negative_slope))
+        return _SEUNetFunction.apply(x, d1, d2, meta, *self.parameters())
+
+
+def get_model():
+    """reference SE_UNet.py:240-242."""
+    net = SE_UNet(in_channel=2)
+    return config, net

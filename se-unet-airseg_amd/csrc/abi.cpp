@@ -1,0 +1,178 @@
+// extern "C" entry points of libseunet_hip.so (per-op part; the whole-network calls live in net.cpp).
+// Thin argument marshalling only: every function validates, forwards to a launcher and returns a status.
+#include "seunet_common.h"
+#include "../../include/seunet_hip.h"
+
+using namespace seunet;
+
+static inline Dims D(seunet_dims d) { return Dims{d.n, d.d, d.h, d.w}; }
+static inline hipStream_t S(seunet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int make_src(int nsrc, const void* const* src, const int* src_c, SrcList& l) {
+  SEUNET_CHECK(nsrc >= 1 && nsrc <= 3 && src && src_c, "bad source list");
+  l = SrcList{};
+  l.n = nsrc;
+  for (int i = 0; i < nsrc; ++i) { l.ptr[i] = src[i]; l.C[i] = src_c[i]; }
+  return 0;
+}
+
+extern "C" {
+
+int seunet_version(void) { return 100; }
+const char* seunet_last_error(void) { return get_error(); }
+
+int seunet_pack_cl(int dtype, const float* in, int c, void* out, int c_pad, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(in && out, "pack_cl: null tensor");
+  return launch_pack_cl(dtype, in, c, out, c_pad, D(dims), S(s));
+}
+int seunet_unpack_cl(int dtype, const void* in, int c, float* out, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(in && out, "unpack_cl: null tensor");
+  return launch_unpack_cl(dtype, in, c, out, D(dims), S(s));
+}
+
+size_t seunet_conv_wpack_bytes(int dtype, int taps, int cin, int cout) { return conv_wpack_bytes(dtype, taps, cin, cout); }
+int seunet_conv_pack_weights(int dtype, const float* w, int taps, int cin, int cout, int tflip, void* wpack, seunet_stream_t s) {
+  SEUNET_CHECK(w && wpack, "conv_pack_weights: null tensor");
+  return launch_conv_pack_weights(dtype, w, taps, cin, cout, tflip, wpack, S(s));
+}
+int seunet_conv_stats_slots(int impl, seunet_dims dims) {
+  return impl == SEUNET_CONV_NAIVE ? epi_partials(D(dims)) : conv_stats_tiles(D(dims));
+}
+int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c, int cin,
+                      const void* weights, int tflip, const float* bias, int ndst, void* const* dst, const int* dst_c,
+                      const int* dst_acc, float* stats_partial, seunet_dims dims, seunet_stream_t s) {
+  SrcList sl;
+  if (int e = make_src(nsrc, src, src_c, sl)) return e;
+  SEUNET_CHECK(ndst >= 1 && ndst <= 3 && dst && dst_c && weights, "conv3d_fwd: bad destination list / weights");
+  DstList dl{};
+  dl.n = ndst;
+  for (int i = 0; i < ndst; ++i) { dl.ptr[i] = dst[i]; dl.C[i] = dst_c[i]; dl.acc[i] = dst_acc ? dst_acc[i] : 0; }
+  if (impl == SEUNET_CONV_NAIVE) {
+    if (int e = launch_conv_naive(dtype, taps, dilation, sl, cin, (const float*)weights, tflip, bias, dl, D(dims), S(s))) return e;
+    if (stats_partial) {
+      SEUNET_CHECK(ndst == 1, "conv3d_fwd: statistics need a single destination");
+      return launch_channel_stats(dtype, dst[0], dst_c[0], stats_partial, D(dims), S(s));
+    }
+    return 0;
+  }
+  return launch_conv_igemm(dtype, taps, dilation, sl, cin, weights, bias, dl, stats_partial, D(dims), S(s));
+}
+size_t seunet_conv3d_wgrad_workspace_bytes(int taps, int cin, int cout) { return wgrad_workspace_bytes(taps, cin, cout); }
+int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c, int cin,
+                        const void* dy, int cout, float* dw, void* workspace, size_t workspace_bytes, seunet_dims dims,
+                        seunet_stream_t s) {
+  SrcList sl;
+  if (int e = make_src(nsrc, src, src_c, sl)) return e;
+  SEUNET_CHECK(dy && dw, "conv3d_wgrad: null tensor");
+  if (impl == SEUNET_CONV_NAIVE) return launch_wgrad_naive(dtype, taps, dilation, sl, cin, dy, cout, dw, D(dims), S(s));
+  SEUNET_CHECK(workspace, "conv3d_wgrad: null workspace");
+  return launch_wgrad(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s));
+}
+
+int seunet_epilogue_slots(seunet_dims dims) { return epi_partials(D(dims)); }
+int seunet_channel_stats(int dtype, const void* t, int c, float* partial, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(t && partial, "channel_stats: null tensor");
+  return launch_channel_stats(dtype, t, c, partial, D(dims), S(s));
+}
+int seunet_stats_finalize(const float* partial, int slots, int c, int n, long long count, float eps, int mode, float* out_a,
+                          float* out_b, seunet_stream_t s) {
+  SEUNET_CHECK(partial && out_a && out_b && slots >= 1 && count >= 1, "stats_finalize: bad argument");
+  return launch_stats_finalize(partial, slots, c, n, count, eps, mode, out_a, out_b, S(s));
+}
+
+int seunet_gate_epilogue_fwd(int dtype, const void* raw, const float* mean, const float* rstd, int c, const float* w_se,
+                             const float* w_se2, const float* w_side, const float* b_side, float slope, void* e_out,
+                             float* side_out, float* level_map, int level_accumulate, const float* head_w, const float* drop,
+                             int drop_stride, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(raw && mean && rstd && w_se && w_side && b_side && e_out, "gate_epilogue_fwd: null tensor");
+  SEUNET_CHECK(!level_map || head_w, "gate_epilogue_fwd: level_map needs head_w");
+  SseParams p{w_se, w_se2, w_side, b_side, slope};
+  SseHead h{side_out, level_map, level_accumulate, head_w, drop, drop_stride};
+  return launch_sse_fwd(dtype, raw, mean, rstd, c, p, e_out, h, D(dims), S(s));
+}
+int seunet_gate_epilogue_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int c, const float* w_se,
+                             const float* w_se2, const float* w_side, const float* b_side, float slope, const void* g_e,
+                             const float* g_side, const float* g_level, const float* head_w, const float* drop, int drop_stride,
+                             void* dxhat_out, float* stat_partial, float* pgrad_partial, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(raw && mean && rstd && w_se && w_side && b_side && dxhat_out && stat_partial && pgrad_partial,
+               "gate_epilogue_bwd: null tensor");
+  SEUNET_CHECK(!g_level || head_w, "gate_epilogue_bwd: g_level needs head_w");
+  SseParams p{w_se, w_se2, w_side, b_side, slope};
+  SseBwdIn g{g_e, g_side, g_level};
+  SseHead h{nullptr, nullptr, 0, head_w, drop, drop_stride};
+  return launch_sse_bwd(dtype, raw, mean, rstd, c, p, g, h, dxhat_out, stat_partial, pgrad_partial, D(dims), S(s));
+}
+int seunet_pgrad_reduce(const float* pgrad_partial, int records, int c, float* dw_se, float* dw_se2, float* dw_side,
+                        float* db_side, float* dhead_w, seunet_stream_t s) {
+  SEUNET_CHECK(pgrad_partial && records >= 1, "pgrad_reduce: bad argument");
+  return launch_pgrad_reduce(pgrad_partial, records, c, dw_se, dw_se2, dw_side, db_side, dhead_w, S(s));
+}
+int seunet_in_bwd(int dtype, void* dx, const void* raw, const float* mean, const float* rstd, const float* m1, const float* m2,
+                  int c, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(dx && raw && mean && rstd && m1 && m2, "in_bwd: null tensor");
+  return launch_in_bwd_apply(dtype, dx, raw, mean, rstd, m1, m2, c, D(dims), S(s));
+}
+
+int seunet_cat_epilogue_fwd(int dtype, const void* raw, const float* mean, const float* rstd, const void* raw2,
+                            const float* mean2, const float* rstd2, int c, float slope, void* out, seunet_dims dims,
+                            seunet_stream_t s) {
+  SEUNET_CHECK(raw && mean && rstd && out && (!raw2 || (mean2 && rstd2)), "cat_epilogue_fwd: null tensor");
+  return launch_cat_fwd(dtype, raw, mean, rstd, raw2, mean2, rstd2, c, slope, out, D(dims), S(s));
+}
+int seunet_cat_epilogue_bwd(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                            const void* raw2, const float* mean2, const float* rstd2, int c, float slope, void* dxhat_out,
+                            void* dxhat2_out, float* stat_partial, float* stat_partial2, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(g_out && raw && mean && rstd && dxhat_out && stat_partial, "cat_epilogue_bwd: null tensor");
+  SEUNET_CHECK(!raw2 || (mean2 && rstd2 && dxhat2_out && stat_partial2), "cat_epilogue_bwd: second branch incomplete");
+  return launch_cat_bwd(dtype, g_out, raw, mean, rstd, raw2, mean2, rstd2, c, slope, dxhat_out, dxhat2_out, stat_partial,
+                        stat_partial2, D(dims), S(s));
+}
+
+int seunet_maxpool_fwd(int dtype, const void* in, int c, void* out, seunet_dims d, seunet_stream_t s) {
+  SEUNET_CHECK(in && out, "maxpool_fwd: null tensor");
+  return launch_maxpool_fwd(dtype, in, c, out, D(d), S(s));
+}
+int seunet_maxpool_bwd(int dtype, const void* in, const void* g_out, int c, void* g_in, int accumulate, seunet_dims d,
+                       seunet_stream_t s) {
+  SEUNET_CHECK(in && g_out && g_in, "maxpool_bwd: null tensor");
+  return launch_maxpool_bwd(dtype, in, g_out, c, g_in, accumulate, D(d), S(s));
+}
+int seunet_upsample2_fwd(int dtype, const void* in, int c, void* out, seunet_dims d, seunet_stream_t s) {
+  SEUNET_CHECK(in && out, "upsample2_fwd: null tensor");
+  return launch_upsample2_fwd(dtype, in, c, out, D(d), S(s));
+}
+int seunet_upsample2_bwd(int dtype, const void* g_out, int c, void* g_in, int accumulate, seunet_dims d, seunet_stream_t s) {
+  SEUNET_CHECK(g_out && g_in, "upsample2_bwd: null tensor");
+  return launch_upsample2_bwd(dtype, g_out, c, g_in, accumulate, D(d), S(s));
+}
+int seunet_side_upsample(const float* side, int c, int scale, float* out, int c_total, int c_off, seunet_dims low,
+                         seunet_stream_t s) {
+  SEUNET_CHECK(side && out && scale >= 1, "side_upsample: bad argument");
+  return launch_side_upsample(side, c, scale, out, c_total, c_off, D(low), S(s));
+}
+
+int seunet_head_fwd(const float* const* level_maps, int nlevels, const float* bias, float* pred, seunet_dims d, seunet_stream_t s) {
+  SEUNET_CHECK(level_maps && bias && pred, "head_fwd: null tensor");
+  return launch_head_fwd(level_maps, nlevels, bias, pred, D(d), S(s));
+}
+size_t seunet_head_bwd_tmp_floats(seunet_dims d) { return head_bwd_tmp_floats(D(d)); }
+int seunet_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, float* tmp, float* g_bias, seunet_dims d,
+                    seunet_stream_t s) {
+  SEUNET_CHECK(g_pred && g_levels && tmp, "head_bwd: null tensor");
+  return launch_head_bwd(g_pred, g_levels, nlevels, tmp, g_bias, D(d), S(s));
+}
+
+int seunet_loss_partial_floats(void) { return loss_partials() * SEUNET_LOSS_NSUMS; }
+int seunet_loss_sums(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
+                     long long n, float* partial, double* sums, seunet_stream_t s) {
+  SEUNET_CHECK(pred && target && partial && sums && n >= 1, "loss_sums: bad argument");
+  return launch_loss_sums(pred, apply_sigmoid, target, weight, skel, n, partial, sums, S(s));
+}
+int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
+                     long long n, const double* sums, float c_dice, float c_gul, float c_atr, float g_scale,
+                     const float* g_scale_dev, float* g_pred, seunet_stream_t s) {
+  SEUNET_CHECK(pred && target && sums && g_pred && n >= 1, "loss_grad: bad argument");
+  return launch_loss_grad(pred, apply_sigmoid, target, weight, skel, n, sums, c_dice, c_gul, c_atr, g_scale, g_scale_dev, g_pred, S(s));
+}
+
+}  // extern "C"

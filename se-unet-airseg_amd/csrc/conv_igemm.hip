@@ -1,0 +1,414 @@
+// Implicit-GEMM convolution for gfx950 matrix cores: 3x3x3 (dilation 1 or 2, "same" zero padding) and
+// 1x1x1, forward and data-gradient (a data-gradient is the same kernel run on flipped/transposed
+// weights).  Reference ops: nn.Conv3d at SE_UNet.py:15,42,57 (+ torch.cat at :186,195,204,212,216,218,
+// 222,224,228 which is fused here as a multi-pointer channel concatenation).
+//
+//   GEMM view     M = voxels, N = output channels, K = taps x input channels
+//   workgroup     256 threads = 4 waves; output tile 4(z) x 4(y) x 32(x) voxels; wave w owns z-slice w,
+//                 i.e. four 32-voxel x-rows, times all N columns of the tile (32 or 64)
+//   MFMA          bf16: v_mfma_f32_32x32x16_bf16 (K-step = 16 channels of one tap)
+//                 f32 : v_mfma_f32_32x32x2_f32   (exact f32 FMA chain; the 1e-3 parity mode)
+//   LDS           input halo tile [(4+2d)(4+2d)(32+2d) voxels][32 B = one K-chunk], 16-B slots XOR-swizzled
+//                 by voxel bit 3 so a ds_read_b128 of 16 consecutive voxels is conflict-free;
+//                 weight slab [tap][k-half][column][8 x bf16] (one contiguous 16-B fragment per lane)
+//   K loop        chunks of 32 bytes of channels (16 bf16 / 8 f32): fill tile + weights, barrier, 27 taps of MFMAs
+//   epilogue      + bias, store (optionally += for gradient accumulation, optionally split over up to three
+//                 destination tensors = backward of the fused concatenation), per-(n,c) InstanceNorm partial
+//                 sums taken from the f32 accumulators (wave shuffle + fixed-order cross-wave sum)
+#include "seunet_common.h"
+
+namespace seunet {
+
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int CV_TZ = 4, CV_TY = 4, CV_TX = 32;
+
+struct ConvKArgs {
+  const void* src0; const void* src1; const void* src2;
+  int srcC0, srcC1, srcC2;
+  int cum1, cum2;            // first virtual channel of source 1 / 2
+  int cin;                   // valid input channels
+  const void* wpack;
+  const float* bias;
+  void* dst0; void* dst1; void* dst2;
+  int dstC0, dstC1, dstC2;
+  int dcum1, dcum2;
+  int dacc0, dacc1, dacc2;
+  int cout;
+  float* stats;
+  int N, D, H, W;
+  int tx, ty, tz;            // tile counts
+  int nchunks;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { static constexpr int KC = 16, KSTEPS = 1; };
+template <> struct Frag<float> { static constexpr int KC = 8, KSTEPS = 4; };
+
+template <typename T, int NSUB, int TAPS, int DIL>
+__global__ void __launch_bounds__(256)
+conv_igemm_kernel(ConvKArgs a) {
+  constexpr int KC = Frag<T>::KC, KSTEPS = Frag<T>::KSTEPS;
+  constexpr int HALO = (TAPS == 27) ? DIL : 0;
+  constexpr int HZ = CV_TZ + 2 * HALO, HY = CV_TY + 2 * HALO, HX = CV_TX + 2 * HALO;
+  constexpr int NVH = HZ * HY * HX;
+  constexpr int NCOL = 32 * NSUB;
+  constexpr int T3 = (TAPS == 27) ? 3 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* in_tile = smem;
+  unsigned char* w_tile = smem + NVH * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  int t = blockIdx.x;
+  const int bx = t % a.tx; t /= a.tx;
+  const int by = t % a.ty;
+  const int bz = t / a.ty;
+  const int x0 = bx * CV_TX, y0 = by * CV_TY, z0 = bz * CV_TZ;
+  const int ntile = blockIdx.y, n = blockIdx.z;
+  const long long V = (long long)a.D * a.H * a.W;
+
+  f32x16 acc[4][NSUB];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    __syncthreads();
+    // ---- stage the input halo tile for this K-chunk (zero padding outside the volume) ----
+    for (int idx = tid; idx < NVH * 2; idx += 256) {
+      const int vox = idx >> 1, piece = idx & 1;
+      const int hx = vox % HX;
+      const int r2 = vox / HX;
+      const int hy = r2 % HY, hz = r2 / HY;
+      const int gz = z0 - HALO + hz, gy = y0 - HALO + hy, gx = x0 - HALO + hx;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      const int ch0 = chunk * KC + piece * (KC / 2);
+      if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+          ch0 < a.cin) {
+        const void* sp = a.src0; int sC = a.srcC0, c = ch0;
+        if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
+        else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
+        const T* p = reinterpret_cast<const T*>(sp) +
+                     ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * sC + c;
+        val = *reinterpret_cast<const uint4*>(p);
+      }
+      *reinterpret_cast<uint4*>(in_tile + vox * 32 + 16 * (piece ^ ((vox >> 3) & 1))) = val;
+    }
+    // ---- stage this chunk's weight slab (pre-packed as the exact LDS image) ----
+    {
+      const uint4* wsrc = reinterpret_cast<const uint4*>(
+          reinterpret_cast<const unsigned char*>(a.wpack) +
+          (size_t)(ntile * a.nchunks + chunk) * (size_t)(TAPS * NCOL * 32));
+      for (int idx = tid; idx < TAPS * NCOL * 2; idx += 256) reinterpret_cast<uint4*>(w_tile)[idx] = wsrc[idx];
+    }
+    __syncthreads();
+
+    // ---- MFMA over taps ----
+    for (int tz3 = 0; tz3 < T3; ++tz3) {
+#pragma unroll
+      for (int ty3 = 0; ty3 < T3; ++ty3) {
+#pragma unroll
+        for (int tx3 = 0; tx3 < T3; ++tx3) {
+          const int tap = (tz3 * T3 + ty3) * T3 + tx3;
+          const int vbase = ((wave + tz3 * HALO) * HY + ty3 * HALO) * HX + tx3 * HALO + col;
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            if constexpr (sizeof(T) == 2) {
+              bf16x8 bfr[NSUB];
+#pragma unroll
+              for (int ns = 0; ns < NSUB; ++ns)
+                bfr[ns] = *reinterpret_cast<const bf16x8*>(w_tile + ((tap * 2 + h) * NCOL + ns * 32 + col) * 16);
+#pragma unroll
+              for (int ms = 0; ms < 4; ++ms) {
+                const int vox = vbase + ms * HX;
+                const bf16x8 afr =
+                    *reinterpret_cast<const bf16x8*>(in_tile + vox * 32 + 16 * (h ^ ((vox >> 3) & 1)));
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[ns], acc[ms][ns], 0, 0, 0);
+              }
+            } else {
+              float bfr[NSUB];
+#pragma unroll
+              for (int ns = 0; ns < NSUB; ++ns)
+                bfr[ns] = *reinterpret_cast<const float*>(w_tile + (((tap * 4 + ks) * 2 + h) * NCOL + ns * 32 + col) * 4);
+#pragma unroll
+              for (int ms = 0; ms < 4; ++ms) {
+                const int vox = vbase + ms * HX;
+                const float afr = *reinterpret_cast<const float*>(
+                    in_tile + vox * 32 + 16 * ((ks >> 1) ^ ((vox >> 3) & 1)) + 4 * (2 * (ks & 1) + h));
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr, bfr[ns], acc[ms][ns], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, store / accumulate, InstanceNorm partial sums ----
+  const int gz = z0 + wave;
+  float s1[NSUB], s2[NSUB];
+#pragma unroll
+  for (int ns = 0; ns < NSUB; ++ns) {
+    s1[ns] = 0.f; s2[ns] = 0.f;
+    const int co = ntile * NCOL + ns * 32 + col;
+    const bool cvalid = co < a.cout;
+    void* dpv = a.dst0; int dC = a.dstC0, dacc = a.dacc0, cl = co;
+    if (co >= a.dcum2) { dpv = a.dst2; dC = a.dstC2; dacc = a.dacc2; cl = co - a.dcum2; }
+    else if (co >= a.dcum1) { dpv = a.dst1; dC = a.dstC1; dacc = a.dacc1; cl = co - a.dcum1; }
+    T* dp = reinterpret_cast<T*>(dpv);
+    const float bias = (a.bias != nullptr && cvalid) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      const int gy = y0 + ms;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool inb = cvalid && gz < a.D && gy < a.H && gx < a.W;
+        float val = acc[ms][ns][r] + bias;
+        if (inb) {
+          s1[ns] += val;
+          s2[ns] += val * val;
+          if (dp != nullptr) {
+            T* q = dp + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * dC + cl;
+            if (dacc) val += to_f32(*q);
+            *q = from_f32<T>(val);
+          }
+        }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    __syncthreads();  // all waves are done reading the tiles; reuse LDS
+    float* red = reinterpret_cast<float*>(smem);  // [4][NCOL][2]
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      const float u = s1[ns] + __shfl_xor(s1[ns], 32, 64);
+      const float v = s2[ns] + __shfl_xor(s2[ns], 32, 64);
+      if (h == 0) {
+        red[(wave * NCOL + ns * 32 + col) * 2] = u;
+        red[(wave * NCOL + ns * 32 + col) * 2 + 1] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < NCOL * 2) {
+      const int c = tid >> 1, k = tid & 1;
+      const int co = ntile * NCOL + c;
+      if (co < a.cout) {
+        const float tot = ((red[(0 * NCOL + c) * 2 + k] + red[(1 * NCOL + c) * 2 + k]) +
+                           red[(2 * NCOL + c) * 2 + k]) + red[(3 * NCOL + c) * 2 + k];
+        a.stats[(((long long)n * gridDim.x + blockIdx.x) * a.cout + co) * 2 + k] = tot;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: PyTorch (Cout, Cin, kD, kH, kW) f32  ->  per (n-tile, K-chunk) LDS images
+// transpose_flip = 1 builds the data-gradient operator (roles of Cin/Cout swapped, taps mirrored)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv_pack_kernel(const float* __restrict__ w, int taps, int cin_w, int cout_w, int tflip,
+                                 T* __restrict__ out, int cin_e, int cout_e, int nchunks, int ncol,
+                                 long long total) {
+  constexpr int KC = Frag<T>::KC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    int ci_in_chunk, col;
+    if (sizeof(T) == 2) {  // [tap][h][col][j]
+      const int j = (int)(r % 8); r /= 8;
+      col = (int)(r % ncol); r /= ncol;
+      const int hh = (int)(r % 2); r /= 2;
+      ci_in_chunk = 8 * hh + j;
+    } else {               // [tap][ks][h][col]
+      col = (int)(r % ncol); r /= ncol;
+      const int hh = (int)(r % 2); r /= 2;
+      const int ks = (int)(r % 4); r /= 4;
+      ci_in_chunk = 2 * ks + hh;
+    }
+    const int tap = (int)(r % taps); r /= taps;
+    const int chunk = (int)(r % nchunks);
+    const int ntile = (int)(r / nchunks);
+    const int ci = chunk * KC + ci_in_chunk, co = ntile * ncol + col;
+    float v = 0.f;
+    if (ci < cin_e && co < cout_e) {
+      if (!tflip) v = w[((long long)co * cin_w + ci) * taps + tap];
+      else v = w[((long long)ci * cin_w + co) * taps + (taps - 1 - tap)];
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+
+static inline int conv_ncol(int cout_e) { return cout_e > 32 ? 64 : 32; }
+static inline int conv_kc(int dtype) { return dtype == SEUNET_BF16 ? 16 : 8; }
+
+size_t conv_wpack_bytes(int dtype, int taps, int cin, int cout) {
+  const int ncol = conv_ncol(cout), ntiles = cdiv(cout, ncol), nchunks = cdiv(cin, conv_kc(dtype));
+  return (size_t)ntiles * nchunks * taps * ncol * 32;
+}
+
+int launch_conv_pack_weights(int dtype, const float* w, int taps, int cin_w, int cout_w, int tflip,
+                             void* wpack, hipStream_t s) {
+  SEUNET_CHECK(taps == 27 || taps == 1, "conv pack: taps=%d unsupported", taps);
+  const int cin_e = tflip ? cout_w : cin_w, cout_e = tflip ? cin_w : cout_w;
+  const int ncol = conv_ncol(cout_e), nchunks = cdiv(cin_e, conv_kc(dtype));
+  const long long total = (long long)(conv_wpack_bytes(dtype, taps, cin_e, cout_e) / dtype_size(dtype));
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == SEUNET_BF16)
+    conv_pack_kernel<bf16_t><<<grid, 256, 0, s>>>(w, taps, cin_w, cout_w, tflip, (bf16_t*)wpack, cin_e, cout_e, nchunks, ncol, total);
+  else
+    conv_pack_kernel<float><<<grid, 256, 0, s>>>(w, taps, cin_w, cout_w, tflip, (float*)wpack, cin_e, cout_e, nchunks, ncol, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int conv_stats_tiles(Dims d) { return cdiv(d.D, CV_TZ) * cdiv(d.H, CV_TY) * cdiv(d.W, CV_TX); }
+
+template <typename T, int NSUB, int TAPS, int DIL>
+static int launch_one(const ConvKArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int HALO = (TAPS == 27) ? DIL : 0;
+  constexpr int NVH = (CV_TZ + 2 * HALO) * (CV_TY + 2 * HALO) * (CV_TX + 2 * HALO);
+  constexpr int LDS = (NVH + TAPS * 32 * NSUB) * 32;
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, NSUB, TAPS, DIL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    configured = true;
+  }
+  conv_igemm_kernel<T, NSUB, TAPS, DIL><<<grid, 256, LDS, s>>>(a);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int launch_t(int taps, int dil, int nsub, const ConvKArgs& a, dim3 grid, hipStream_t s) {
+  if (taps == 1) return nsub == 1 ? launch_one<T, 1, 1, 1>(a, grid, s) : launch_one<T, 2, 1, 1>(a, grid, s);
+  if (dil == 1) return nsub == 1 ? launch_one<T, 1, 27, 1>(a, grid, s) : launch_one<T, 2, 27, 1>(a, grid, s);
+  return nsub == 1 ? launch_one<T, 1, 27, 2>(a, grid, s) : launch_one<T, 2, 27, 2>(a, grid, s);
+}
+
+static int check_lists(const SrcList& src, const DstList& dst) {
+  SEUNET_CHECK(src.n >= 1 && src.n <= 3 && dst.n >= 1 && dst.n <= 3, "conv: 1..3 sources/destinations");
+  for (int i = 0; i < src.n; ++i)
+    SEUNET_CHECK(src.C[i] > 0 && src.C[i] % 8 == 0 && src.ptr[i], "conv: source %d needs C %% 8 == 0 (got %d)", i, src.C[i]);
+  for (int i = 0; i < dst.n; ++i)
+    SEUNET_CHECK(dst.C[i] > 0 && dst.C[i] % 8 == 0, "conv: destination %d needs C %% 8 == 0 (got %d)", i, dst.C[i]);
+  return 0;
+}
+
+int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_logical, const void* wpack,
+                      const float* bias, const DstList& dst, float* stats, Dims d, hipStream_t s) {
+  if (int e = check_lists(src, dst)) return e;
+  SEUNET_CHECK(cin_logical >= 1 && cin_logical <= src.total(), "conv: cin=%d exceeds the source channels %d", cin_logical, src.total());
+  SEUNET_CHECK(taps == 27 || taps == 1, "conv: taps=%d unsupported", taps);
+  SEUNET_CHECK(taps == 1 || dil == 1 || dil == 2, "conv: dilation %d unsupported", dil);
+  ConvKArgs a{};
+  a.src0 = src.ptr[0]; a.srcC0 = src.C[0];
+  a.src1 = src.n > 1 ? src.ptr[1] : nullptr; a.srcC1 = src.n > 1 ? src.C[1] : 0;
+  a.src2 = src.n > 2 ? src.ptr[2] : nullptr; a.srcC2 = src.n > 2 ? src.C[2] : 0;
+  a.cin = cin_logical;
+  a.cum1 = src.n > 1 ? src.C[0] : src.total();
+  a.cum2 = src.n > 2 ? src.C[0] + src.C[1] : src.total();
+  a.wpack = wpack; a.bias = bias;
+  a.dst0 = dst.ptr[0]; a.dstC0 = dst.C[0]; a.dacc0 = dst.acc[0];
+  a.dst1 = dst.n > 1 ? dst.ptr[1] : nullptr; a.dstC1 = dst.n > 1 ? dst.C[1] : 0; a.dacc1 = dst.n > 1 ? dst.acc[1] : 0;
+  a.dst2 = dst.n > 2 ? dst.ptr[2] : nullptr; a.dstC2 = dst.n > 2 ? dst.C[2] : 0; a.dacc2 = dst.n > 2 ? dst.acc[2] : 0;
+  a.cout = dst.total();
+  a.dcum1 = dst.n > 1 ? dst.C[0] : a.cout;
+  a.dcum2 = dst.n > 2 ? dst.C[0] + dst.C[1] : a.cout;
+  a.stats = stats;
+  a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
+  a.tx = cdiv(d.W, CV_TX); a.ty = cdiv(d.H, CV_TY); a.tz = cdiv(d.D, CV_TZ);
+  a.nchunks = cdiv(a.cin, conv_kc(dtype));
+  const int ncol = conv_ncol(a.cout);
+  dim3 grid(a.tx * a.ty * a.tz, cdiv(a.cout, ncol), d.N);
+  SEUNET_CHECK(d.N <= 65535, "conv: batch too large");
+  if (dtype == SEUNET_BF16) return launch_t<bf16_t>(taps, dil, ncol / 32, a, grid, s);
+  return launch_t<float>(taps, dil, ncol / 32, a, grid, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// naive direct convolution (one thread per output element).  Device-side cross-check for the MFMA
+// kernel and selectable with SEUNET_CONV_IMPL=naive; never a CPU fallback.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv_naive_kernel(ConvKArgs a, const float* __restrict__ w, int taps, int dil, int tflip,
+                                  int cin_w, long long total) {
+  const long long V = (long long)a.D * a.H * a.W;
+  const int t3 = taps == 27 ? 3 : 1, c = taps == 27 ? 1 : 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % a.cout);
+    long long r = i / a.cout;
+    const int x = (int)(r % a.W); r /= a.W;
+    const int y = (int)(r % a.H); r /= a.H;
+    const int z = (int)(r % a.D);
+    const long long n = r / a.D;
+    float acc = a.bias ? a.bias[co] : 0.f;
+    for (int tap = 0; tap < taps; ++tap) {
+      const int dz = (tap / (t3 * t3) - c) * dil, dy = ((tap / t3) % t3 - c) * dil, dx = (tap % t3 - c) * dil;
+      const int zz = z + dz, yy = y + dy, xx = x + dx;
+      if ((unsigned)zz >= (unsigned)a.D || (unsigned)yy >= (unsigned)a.H || (unsigned)xx >= (unsigned)a.W) continue;
+      const long long vv = n * V + ((long long)zz * a.H + yy) * a.W + xx;
+      for (int ci = 0; ci < a.cin; ++ci) {
+        const void* sp = a.src0; int sC = a.srcC0, cc = ci;
+        if (ci >= a.cum2) { sp = a.src2; sC = a.srcC2; cc = ci - a.cum2; }
+        else if (ci >= a.cum1) { sp = a.src1; sC = a.srcC1; cc = ci - a.cum1; }
+        const float xv = to_f32(reinterpret_cast<const T*>(sp)[vv * sC + cc]);
+        const float wv = tflip ? w[((long long)ci * cin_w + co) * taps + (taps - 1 - tap)]
+                               : w[((long long)co * cin_w + ci) * taps + tap];
+        acc += xv * wv;
+      }
+    }
+    void* dpv = a.dst0; int dC = a.dstC0, dacc = a.dacc0, cl = co;
+    if (co >= a.dcum2) { dpv = a.dst2; dC = a.dstC2; dacc = a.dacc2; cl = co - a.dcum2; }
+    else if (co >= a.dcum1) { dpv = a.dst1; dC = a.dstC1; dacc = a.dacc1; cl = co - a.dcum1; }
+    if (dpv == nullptr) continue;
+    T* q = reinterpret_cast<T*>(dpv) + (n * V + ((long long)z * a.H + y) * a.W + x) * dC + cl;
+    if (dacc) acc += to_f32(*q);
+    *q = from_f32<T>(acc);
+  }
+}
+
+// Weights are in the PyTorch layout.  cin_logical = number of (leading) input channels that carry weights;
+// tensors may be zero-padded beyond it (the packed network input).
+int launch_conv_naive(int dtype, int taps, int dil, const SrcList& src, int cin_logical, const float* w,
+                      int tflip, const float* bias, const DstList& dst, Dims d, hipStream_t s) {
+  if (int e = check_lists(src, dst)) return e;
+  SEUNET_CHECK(cin_logical >= 1 && cin_logical <= src.total(), "conv: cin=%d exceeds the source channels %d", cin_logical, src.total());
+  ConvKArgs a{};
+  a.src0 = src.ptr[0]; a.srcC0 = src.C[0];
+  a.src1 = src.n > 1 ? src.ptr[1] : nullptr; a.srcC1 = src.n > 1 ? src.C[1] : 0;
+  a.src2 = src.n > 2 ? src.ptr[2] : nullptr; a.srcC2 = src.n > 2 ? src.C[2] : 0;
+  a.cin = cin_logical;
+  a.cum1 = src.n > 1 ? src.C[0] : src.total();
+  a.cum2 = src.n > 2 ? src.C[0] + src.C[1] : src.total();
+  a.bias = bias;
+  a.dst0 = dst.ptr[0]; a.dstC0 = dst.C[0]; a.dacc0 = dst.acc[0];
+  a.dst1 = dst.n > 1 ? dst.ptr[1] : nullptr; a.dstC1 = dst.n > 1 ? dst.C[1] : 0; a.dacc1 = dst.n > 1 ? dst.acc[1] : 0;
+  a.dst2 = dst.n > 2 ? dst.ptr[2] : nullptr; a.dstC2 = dst.n > 2 ? dst.C[2] : 0; a.dacc2 = dst.n > 2 ? dst.acc[2] : 0;
+  a.cout = dst.total();
+  a.dcum1 = dst.n > 1 ? dst.C[0] : a.cout;
+  a.dcum2 = dst.n > 2 ? dst.C[0] + dst.C[1] : a.cout;
+  a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
+  const long long total = (long long)d.N * d.vox() * a.cout;
+  const int grid = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+  const int cin_w = tflip ? a.cout : cin_logical;  // the PyTorch weight's Cin extent
+  if (dtype == SEUNET_BF16)
+    conv_naive_kernel<bf16_t><<<grid, 256, 0, s>>>(a, w, taps, dil, tflip, cin_w, total);
+  else
+    conv_naive_kernel<float><<<grid, 256, 0, s>>>(a, w, taps, dil, tflip, cin_w, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace seunet

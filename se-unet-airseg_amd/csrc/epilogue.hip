@@ -1,0 +1,612 @@
+// HBM-bound "epilogue" kernels of the SE-UNet blocks (gfx950).
+//
+//   gated block   (reference SSEConv / SSEConv2, SE_UNet.py:24-35, 68-82):
+//       raw conv output -> InstanceNorm -> LeakyReLU -> spatial gate(s) -> e ; side = conv1x1(e)
+//   aggregation   (reference CATConv, SE_UNet.py:45-49, and the residual adds at :187,196,205):
+//       raw -> InstanceNorm -> LeakyReLU (+ the same for the raw-input "x" branch)
+//   and their backward passes (two-phase InstanceNorm backward).
+//
+// Thread mapping: one lane owns 8 consecutive channels (16 B bf16 / 32 B f32) of one voxel,
+// LPV = C/8 consecutive lanes own one voxel, so every global access is a fully coalesced
+// 16/32-byte-per-lane stream; the per-voxel channel dot products of the gates are LPV-lane
+// xor-shuffle reductions (wave64), the per-(n,c) InstanceNorm sums are strided shuffle
+// reductions + a fixed-order cross-wave sum (deterministic, no atomics).
+#include "seunet_common.h"
+
+namespace seunet {
+
+static constexpr int EPI_THREADS = 256;
+
+int epi_partials(Dims d) {
+  long long v = d.vox();
+  long long p = v / 1024;
+  if (p < 1) p = 1;
+  if (p > 256) p = 256;
+  return (int)p;
+}
+
+// ----------------------------------------------------------------------------------
+// generic per-(n,c) sum / sum of squares of a channels-last tensor
+// ----------------------------------------------------------------------------------
+template <typename T, int LPV>
+__global__ void __launch_bounds__(EPI_THREADS)
+channel_stats_kernel(const T* __restrict__ t, int C, float* __restrict__ partial, long long V) {
+  const int n = blockIdx.y, P = gridDim.x;
+  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
+  constexpr int VPB = EPI_THREADS / LPV;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+    float x[8];
+    load8(t + ((long long)n * V + v) * C + cg * 8, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] += x[j]; s2[j] += x[j] * x[j]; }
+  }
+  __shared__ float red[4][16][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float a = stride_sum<LPV>(s1[j]), b = stride_sum<LPV>(s2[j]);
+    if (lane < LPV) { red[wave][lane][j] = a; red[wave][lane][8 + j] = b; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < LPV * 16; i += EPI_THREADS) {
+    const int g = i / 16, k = i % 16;
+    const float tot = ((red[0][g][k] + red[1][g][k]) + red[2][g][k]) + red[3][g][k];
+    const int c = g * 8 + (k & 7);
+    partial[(((long long)n * P + blockIdx.x) * C + c) * 2 + (k >> 3)] = tot;
+  }
+}
+
+// one wave per (n, c): sums the partial slots in a fixed order in f64
+__global__ void __launch_bounds__(256)
+stats_finalize_kernel(const float* __restrict__ partial, int slots, int C, int N, double inv_count,
+                      float eps, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + wave;  // (n, c)
+  if (idx >= N * C) return;
+  const int n = idx / C, c = idx % C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = lane; p < slots; p += 64) {
+    const float* q = partial + (((long long)n * slots + p) * C + c) * 2;
+    s1 += (double)q[0];
+    s2 += (double)q[1];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  if (lane == 0) {
+    if (mode == 0) {
+      const double mean = s1 * inv_count;
+      double var = s2 * inv_count - mean * mean;  // biased variance (InstanceNorm3d)
+      if (var < 0.0) var = 0.0;
+      out_a[idx] = (float)mean;
+      out_b[idx] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      out_a[idx] = (float)(s1 * inv_count);
+      out_b[idx] = (float)(s2 * inv_count);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// gated block, forward
+// ----------------------------------------------------------------------------------
+template <typename T, int LPV, bool G2>
+__global__ void __launch_bounds__(EPI_THREADS)
+sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
+               const float* __restrict__ rstd, int C, SseParams p, T* __restrict__ e_out,
+               SseHead head, long long V) {
+  const int n = blockIdx.y, P = gridDim.x;
+  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
+  constexpr int VPB = EPI_THREADS / LPV;
+  const int c0 = cg * 8;
+  float mu[8], rs[8], wse[8], wse2[8], w20[8], w21[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[n * C + c0 + j];
+    rs[j] = rstd[n * C + c0 + j];
+    wse[j] = p.w_se[c0 + j];
+    wse2[j] = G2 ? p.w_se2[c0 + j] : 0.f;
+    w20[j] = p.w_side[c0 + j];
+    w21[j] = p.w_side[C + c0 + j];
+  }
+  const float b20 = p.b_side[0], b21 = p.b_side[1], slope = p.slope;
+  float hw0 = 0.f, hw1 = 0.f;
+  if (head.level_map) {
+    hw0 = head.head_w[0] * (head.drop ? head.drop[n * head.drop_stride + 0] : 1.f);
+    hw1 = head.head_w[1] * (head.drop ? head.drop[n * head.drop_stride + 1] : 1.f);
+  }
+  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+    const long long vi = (long long)n * V + v;
+    float x[8], a[8], e[8];
+    load8(raw + vi * C + c0, x);
+    float d1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (x[j] - mu[j]) * rs[j];
+      a[j] = xh > 0.f ? xh : xh * slope;
+      d1 += wse[j] * a[j];
+    }
+    const float g1 = 1.f / (1.f + expf(-group_sum<LPV>(d1)));
+    float d2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e[j] = a[j] * g1;
+      d2 += wse2[j] * e[j];
+    }
+    if (G2) {
+      const float g2 = 1.f / (1.f + expf(-group_sum<LPV>(d2)));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] *= g2;
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0 += w20[j] * e[j]; s1 += w21[j] * e[j]; }
+    s0 = group_sum<LPV>(s0) + b20;
+    s1 = group_sum<LPV>(s1) + b21;
+    store8(e_out + vi * C + c0, e);
+    if (cg == 0) {
+      if (head.side_out) { head.side_out[vi * 2] = s0; head.side_out[vi * 2 + 1] = s1; }
+      if (head.level_map) {
+        const float t = hw0 * s0 + hw1 * s1;
+        head.level_map[vi] = head.level_accumulate ? head.level_map[vi] + t : t;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// gated block, backward pass A: gradient w.r.t. the normalised activation (dxhat), its
+// InstanceNorm sums, and the gate / side / head parameter gradients
+// ----------------------------------------------------------------------------------
+template <typename T, int LPV, bool G2>
+__global__ void __launch_bounds__(EPI_THREADS)
+sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
+               const float* __restrict__ rstd, int C, SseParams p, SseBwdIn g, SseHead head,
+               T* dxhat_out, float* __restrict__ stat_partial,
+               float* __restrict__ pgrad_partial, long long V) {
+  const int n = blockIdx.y, P = gridDim.x;
+  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
+  constexpr int VPB = EPI_THREADS / LPV;
+  const int c0 = cg * 8;
+  float mu[8], rs[8], wse[8], wse2[8], w20[8], w21[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[n * C + c0 + j];
+    rs[j] = rstd[n * C + c0 + j];
+    wse[j] = p.w_se[c0 + j];
+    wse2[j] = G2 ? p.w_se2[c0 + j] : 0.f;
+    w20[j] = p.w_side[c0 + j];
+    w21[j] = p.w_side[C + c0 + j];
+  }
+  const float b20 = p.b_side[0], b21 = p.b_side[1], slope = p.slope;
+  float dr0 = 1.f, dr1 = 1.f, hw0 = 0.f, hw1 = 0.f;
+  if (g.g_level) {
+    if (head.drop) { dr0 = head.drop[n * head.drop_stride]; dr1 = head.drop[n * head.drop_stride + 1]; }
+    hw0 = head.head_w[0] * dr0;
+    hw1 = head.head_w[1] * dr1;
+  }
+  float sdx[8], sdxx[8], awse[8], awse2[8], aw20[8], aw21[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sdx[j] = sdxx[j] = awse[j] = awse2[j] = aw20[j] = aw21[j] = 0.f; }
+  float adb0 = 0.f, adb1 = 0.f, adh0 = 0.f, adh1 = 0.f;
+
+  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+    const long long vi = (long long)n * V + v;
+    float x[8], xh[8], a[8], b[8], e[8], de[8];
+    load8(raw + vi * C + c0, x);
+    float d1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xh[j] = (x[j] - mu[j]) * rs[j];
+      a[j] = xh[j] > 0.f ? xh[j] : xh[j] * slope;
+      d1 += wse[j] * a[j];
+    }
+    const float g1 = 1.f / (1.f + expf(-group_sum<LPV>(d1)));
+    float d2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { b[j] = a[j] * g1; d2 += wse2[j] * b[j]; }
+    float g2 = 1.f;
+    if (G2) g2 = 1.f / (1.f + expf(-group_sum<LPV>(d2)));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = G2 ? b[j] * g2 : b[j];
+
+    // gradient arriving through the 2-channel side output
+    float ds0 = 0.f, ds1 = 0.f;
+    if (g.g_level) {
+      const float gl = g.g_level[vi];
+      ds0 = hw0 * gl;
+      ds1 = hw1 * gl;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s0 += w20[j] * e[j]; s1 += w21[j] * e[j]; }
+      s0 = group_sum<LPV>(s0) + b20;
+      s1 = group_sum<LPV>(s1) + b21;
+      if (cg == 0) { adh0 += gl * dr0 * s0; adh1 += gl * dr1 * s1; }
+    } else if (g.g_side) {
+      ds0 = g.g_side[vi * 2];
+      ds1 = g.g_side[vi * 2 + 1];
+    }
+    if (cg == 0) { adb0 += ds0; adb1 += ds1; }
+    if (g.g_e) {
+      load8(reinterpret_cast<const T*>(g.g_e) + vi * C + c0, de);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) de[j] = 0.f;
+    }
+    float t2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      de[j] += w20[j] * ds0 + w21[j] * ds1;
+      aw20[j] += ds0 * e[j];
+      aw21[j] += ds1 * e[j];
+      t2 += de[j] * b[j];
+    }
+    if (G2) {  // e = b * g2, g2 = sigmoid(<w_se2, b>)
+      const float q2 = group_sum<LPV>(t2) * g2 * (1.f - g2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        awse2[j] += q2 * b[j];
+        de[j] = de[j] * g2 + q2 * wse2[j];  // now d/db
+      }
+    }
+    float t1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t1 += de[j] * a[j];
+    const float q1 = group_sum<LPV>(t1) * g1 * (1.f - g1);  // b = a * g1, g1 = sigmoid(<w_se, a>)
+    float dxh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      awse[j] += q1 * a[j];
+      const float da = de[j] * g1 + q1 * wse[j];
+      dxh[j] = da * (xh[j] > 0.f ? 1.f : slope);
+      sdx[j] += dxh[j];
+      sdxx[j] += dxh[j] * xh[j];
+    }
+    store8(dxhat_out + vi * C + c0, dxh);
+  }
+
+  // ---- block reduction (fixed order) ----
+  __shared__ float red[4][16][48];
+  __shared__ float reds[4][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float r0 = stride_sum<LPV>(sdx[j]), r1 = stride_sum<LPV>(sdxx[j]);
+    const float r2 = stride_sum<LPV>(awse[j]), r3 = stride_sum<LPV>(awse2[j]);
+    const float r4 = stride_sum<LPV>(aw20[j]), r5 = stride_sum<LPV>(aw21[j]);
+    if (lane < LPV) {
+      red[wave][lane][j] = r0;      red[wave][lane][8 + j] = r1;
+      red[wave][lane][16 + j] = r2; red[wave][lane][24 + j] = r3;
+      red[wave][lane][32 + j] = r4; red[wave][lane][40 + j] = r5;
+    }
+  }
+  {
+    const float q0 = stride_sum<1>(adb0), q1 = stride_sum<1>(adb1);
+    const float q2 = stride_sum<1>(adh0), q3 = stride_sum<1>(adh1);
+    if (lane == 0) { reds[wave][0] = q0; reds[wave][1] = q1; reds[wave][2] = q2; reds[wave][3] = q3; }
+  }
+  __syncthreads();
+  const long long rec = (long long)n * P + blockIdx.x;
+  float* pg = pgrad_partial + rec * (4 * C + 4);
+  for (int i = threadIdx.x; i < LPV * 48; i += EPI_THREADS) {
+    const int gq = i / 48, k = i % 48;
+    const float tot = ((red[0][gq][k] + red[1][gq][k]) + red[2][gq][k]) + red[3][gq][k];
+    const int c = gq * 8 + (k & 7);
+    switch (k >> 3) {
+      case 0: stat_partial[(rec * C + c) * 2] = tot; break;
+      case 1: stat_partial[(rec * C + c) * 2 + 1] = tot; break;
+      case 2: pg[c] = tot; break;
+      case 3: pg[C + c] = tot; break;
+      case 4: pg[2 * C + c] = tot; break;
+      default: pg[3 * C + c] = tot; break;
+    }
+  }
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    pg[4 * C + k] = ((reds[0][k] + reds[1][k]) + reds[2][k]) + reds[3][k];
+  }
+}
+
+// sums the per-block parameter-gradient records; one wave per entry, f64, fixed order
+__global__ void __launch_bounds__(256)
+pgrad_reduce_kernel(const float* __restrict__ pg, int records, int C, float* dw_se, float* dw_se2,
+                    float* dw_side, float* db_side, float* dhead_w) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + wave, K = 4 * C + 4;
+  if (k >= K) return;
+  double s = 0.0;
+  for (int r = lane; r < records; r += 64) s += (double)pg[(long long)r * K + k];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane != 0) return;
+  const float v = (float)s;
+  if (k < C) { if (dw_se) dw_se[k] = v; }
+  else if (k < 2 * C) { if (dw_se2) dw_se2[k - C] = v; }
+  else if (k < 4 * C) { if (dw_side) dw_side[k - 2 * C] = v; }
+  else if (k < 4 * C + 2) { if (db_side) db_side[k - 4 * C] = v; }
+  else { if (dhead_w) dhead_w[k - 4 * C - 2] = v; }
+}
+
+// ----------------------------------------------------------------------------------
+// InstanceNorm backward, pass B:  draw = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat))
+// ----------------------------------------------------------------------------------
+template <typename T, int LPV>
+__global__ void __launch_bounds__(EPI_THREADS)
+in_bwd_apply_kernel(T* __restrict__ dx, const T* __restrict__ raw, const float* __restrict__ mean,
+                    const float* __restrict__ rstd, const float* __restrict__ m1,
+                    const float* __restrict__ m2, int C, long long V) {
+  const int n = blockIdx.y, P = gridDim.x;
+  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
+  constexpr int VPB = EPI_THREADS / LPV;
+  const int c0 = cg * 8;
+  float mu[8], rs[8], a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
+    a1[j] = m1[n * C + c0 + j];   a2[j] = m2[n * C + c0 + j];
+  }
+  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+    const long long o = ((long long)n * V + v) * C + c0;
+    float d[8], x[8];
+    load8(dx + o, d);
+    load8(raw + o, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (x[j] - mu[j]) * rs[j];
+      d[j] = rs[j] * (d[j] - a1[j] - xh * a2[j]);
+    }
+    store8(dx + o, d);
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// aggregation block (1x1x1 conv output -> IN -> LeakyReLU, optional second branch added)
+// ----------------------------------------------------------------------------------
+template <typename T, int LPV, bool TWO>
+__global__ void __launch_bounds__(EPI_THREADS)
+cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
+               const float* __restrict__ rstd, const T* __restrict__ raw2,
+               const float* __restrict__ mean2, const float* __restrict__ rstd2, int C, float slope,
+               T* __restrict__ out, long long V) {
+  const int n = blockIdx.y, P = gridDim.x;
+  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
+  constexpr int VPB = EPI_THREADS / LPV;
+  const int c0 = cg * 8;
+  float mu[8], rs[8], mu2[8], rs2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
+    mu2[j] = TWO ? mean2[n * C + c0 + j] : 0.f;
+    rs2[j] = TWO ? rstd2[n * C + c0 + j] : 0.f;
+  }
+  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+    const long long o = ((long long)n * V + v) * C + c0;
+    float x[8], y[8];
+    load8(raw + o, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (x[j] - mu[j]) * rs[j];
+      y[j] = xh > 0.f ? xh : xh * slope;
+    }
+    if (TWO) {
+      load8(raw2 + o, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (x[j] - mu2[j]) * rs2[j];
+        y[j] += xh > 0.f ? xh : xh * slope;
+      }
+    }
+    store8(out + o, y);
+  }
+}
+
+template <typename T, int LPV, bool TWO>
+__global__ void __launch_bounds__(EPI_THREADS)
+cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
+               const float* __restrict__ mean, const float* __restrict__ rstd,
+               const T* __restrict__ raw2, const float* __restrict__ mean2,
+               const float* __restrict__ rstd2, int C, float slope, T* dxhat_out,
+               T* dxhat2_out, float* __restrict__ stat_partial,
+               float* __restrict__ stat_partial2, long long V) {
+  const int n = blockIdx.y, P = gridDim.x;
+  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
+  constexpr int VPB = EPI_THREADS / LPV;
+  const int c0 = cg * 8;
+  float mu[8], rs[8], mu2[8], rs2[8], s[4][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
+    mu2[j] = TWO ? mean2[n * C + c0 + j] : 0.f;
+    rs2[j] = TWO ? rstd2[n * C + c0 + j] : 0.f;
+    s[0][j] = s[1][j] = s[2][j] = s[3][j] = 0.f;
+  }
+  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+    const long long o = ((long long)n * V + v) * C + c0;
+    float gy[8], x[8], d[8];
+    load8(g_out + o, gy);
+    load8(raw + o, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (x[j] - mu[j]) * rs[j];
+      d[j] = gy[j] * (xh > 0.f ? 1.f : slope);
+      s[0][j] += d[j];
+      s[1][j] += d[j] * xh;
+    }
+    if (TWO) {
+      float d2[8];
+      load8(raw2 + o, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (x[j] - mu2[j]) * rs2[j];
+        d2[j] = gy[j] * (xh > 0.f ? 1.f : slope);
+        s[2][j] += d2[j];
+        s[3][j] += d2[j] * xh;
+      }
+      store8(dxhat2_out + o, d2);
+    }
+    store8(dxhat_out + o, d);  // may alias g_out (same element, read before write)
+  }
+  __shared__ float red[4][16][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float r = stride_sum<LPV>(s[q][j]);
+      if (lane < LPV) red[wave][lane][q * 8 + j] = r;
+    }
+  __syncthreads();
+  const long long rec = (long long)n * P + blockIdx.x;
+  for (int i = threadIdx.x; i < LPV * 32; i += EPI_THREADS) {
+    const int gq = i / 32, k = i % 32, q = k >> 3;
+    const float tot = ((red[0][gq][k] + red[1][gq][k]) + red[2][gq][k]) + red[3][gq][k];
+    const int c = gq * 8 + (k & 7);
+    if (q < 2) stat_partial[(rec * C + c) * 2 + q] = tot;
+    else if (TWO) stat_partial2[(rec * C + c) * 2 + (q - 2)] = tot;
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// launchers
+// ----------------------------------------------------------------------------------
+#define SEUNET_LPV_SWITCH(LPVVAL, ...)                                                  \
+  switch (LPVVAL) {                                                                       \
+    case 1: { constexpr int LPV = 1; __VA_ARGS__; } break;                                       \
+    case 2: { constexpr int LPV = 2; __VA_ARGS__; } break;                                       \
+    case 4: { constexpr int LPV = 4; __VA_ARGS__; } break;                                       \
+    case 8: { constexpr int LPV = 8; __VA_ARGS__; } break;                                       \
+    case 16: { constexpr int LPV = 16; __VA_ARGS__; } break;                                     \
+    default: return fail("unsupported channel count %d (need 8,16,32,64 or 128)", (LPVVAL)*8); \
+  }
+
+static int check_c(int C) {
+  SEUNET_CHECK(C % 8 == 0 && C >= 8 && C <= 128 && (C & (C - 1)) == 0,
+               "channel count %d must be a power of two in [8,128]", C);
+  return 0;
+}
+
+int launch_channel_stats(int dtype, const void* t, int C, float* partial, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  dim3 grid(epi_partials(d), d.N);
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16)
+      channel_stats_kernel<bf16_t, LPV><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)t, C, partial, d.vox());
+    else
+      channel_stats_kernel<float, LPV><<<grid, EPI_THREADS, 0, s>>>((const float*)t, C, partial, d.vox());
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_stats_finalize(const float* partial, int slots, int C, int N, long long count, float eps,
+                          int mode, float* out_a, float* out_b, hipStream_t s) {
+  stats_finalize_kernel<<<cdiv(N * C, 4), 256, 0, s>>>(partial, slots, C, N, 1.0 / (double)count, eps,
+                                                      mode, out_a, out_b);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sse_fwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
+                   const SseParams& p, void* e_out, const SseHead& head, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  dim3 grid(epi_partials(d), d.N);
+  const bool g2 = p.w_se2 != nullptr;
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16) {
+      if (g2) sse_fwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, (bf16_t*)e_out, head, d.vox());
+      else sse_fwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, (bf16_t*)e_out, head, d.vox());
+    } else {
+      if (g2) sse_fwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, (float*)e_out, head, d.vox());
+      else sse_fwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, (float*)e_out, head, d.vox());
+    }
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
+                   const SseParams& p, const SseBwdIn& g, const SseHead& head, void* dxhat_out,
+                   float* stat_partial, float* pgrad_partial, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  dim3 grid(epi_partials(d), d.N);
+  const bool g2 = p.w_se2 != nullptr;
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16) {
+      if (g2) sse_bwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, g, head, (bf16_t*)dxhat_out, stat_partial, pgrad_partial, d.vox());
+      else sse_bwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, g, head, (bf16_t*)dxhat_out, stat_partial, pgrad_partial, d.vox());
+    } else {
+      if (g2) sse_bwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, g, head, (float*)dxhat_out, stat_partial, pgrad_partial, d.vox());
+      else sse_bwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, g, head, (float*)dxhat_out, stat_partial, pgrad_partial, d.vox());
+    }
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* dw_se, float* dw_se2,
+                        float* dw_side, float* db_side, float* dhead_w, hipStream_t s) {
+  pgrad_reduce_kernel<<<cdiv(4 * C + 4, 4), 256, 0, s>>>(pgrad_partial, records, C, dw_se, dw_se2,
+                                                        dw_side, db_side, dhead_w);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_in_bwd_apply(int dtype, void* dx, const void* raw, const float* mean, const float* rstd,
+                        const float* m1, const float* m2, int C, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  dim3 grid(epi_partials(d) * 4, d.N);
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16)
+      in_bwd_apply_kernel<bf16_t, LPV><<<grid, EPI_THREADS, 0, s>>>((bf16_t*)dx, (const bf16_t*)raw, mean, rstd, m1, m2, C, d.vox());
+    else
+      in_bwd_apply_kernel<float, LPV><<<grid, EPI_THREADS, 0, s>>>((float*)dx, (const float*)raw, mean, rstd, m1, m2, C, d.vox());
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cat_fwd(int dtype, const void* raw, const float* mean, const float* rstd, const void* raw2,
+                   const float* mean2, const float* rstd2, int C, float slope, void* out, Dims d,
+                   hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  dim3 grid(epi_partials(d) * 4, d.N);
+  const bool two = raw2 != nullptr;
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16) {
+      if (two) cat_fwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, (const bf16_t*)raw2, mean2, rstd2, C, slope, (bf16_t*)out, d.vox());
+      else cat_fwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (bf16_t*)out, d.vox());
+    } else {
+      if (two) cat_fwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, (const float*)raw2, mean2, rstd2, C, slope, (float*)out, d.vox());
+      else cat_fwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (float*)out, d.vox());
+    }
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                   const void* raw2, const float* mean2, const float* rstd2, int C, float slope,
+                   void* dxhat_out, void* dxhat2_out, float* stat_partial, float* stat_partial2, Dims d,
+                   hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  dim3 grid(epi_partials(d), d.N);
+  const bool two = raw2 != nullptr;
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16) {
+      if (two) cat_bwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)raw2, mean2, rstd2, C, slope, (bf16_t*)dxhat_out, (bf16_t*)dxhat2_out, stat_partial, stat_partial2, d.vox());
+      else cat_bwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (bf16_t*)dxhat_out, nullptr, stat_partial, nullptr, d.vox());
+    } else {
+      if (two) cat_bwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)raw2, mean2, rstd2, C, slope, (float*)dxhat_out, (float*)dxhat2_out, stat_partial, stat_partial2, d.vox());
+      else cat_bwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (float*)dxhat_out, nullptr, stat_partial, nullptr, d.vox());
+    }
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace seunet

@@ -1,0 +1,501 @@
+// Whole-network executor: SE_UNet.forward (reference SE_UNet.py:181-238) and its backward, as one
+// stream-ordered sequence of the kernels in this directory.  The graph is data (kOps below) and two small
+// interpreters walk it forwards / backwards; nothing here allocates: every intermediate lives at a fixed
+// offset of a caller-owned workspace whose layout is a pure function of seunet_net_desc (so the same
+// layout is recomputed by the backward call).
+#include "seunet_common.h"
+#include "../../include/seunet_hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace seunet {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// parameter registry == the reference's state_dict order (SE_UNet.py:108-151)
+// ---------------------------------------------------------------------------------------------------
+struct BlockDesc { const char* name; char kind; int cin; int cout; };  // cin -1 = in_channel; 'g' one gate, 'G' two, 'c' cat
+const BlockDesc kBlocks[] = {
+    {"ec1", 'g', -1, 8},   {"ec2", 'g', 8, 16},    {"ec3", 'g', 16, 32},  {"ec33", 'c', 56, 32},  {"x33", 'c', -1, 32},
+    {"ec4", 'G', 32, 32},  {"ec5", 'G', 32, 32},   {"ec6", 'G', 32, 64},  {"ec63", 'c', 128, 64}, {"x63", 'c', -1, 64},
+    {"ec7", 'G', 64, 64},  {"ec8", 'G', 64, 64},   {"ec9", 'G', 64, 64},  {"ec93", 'c', 192, 64}, {"x93", 'c', -1, 64},
+    {"ec10", 'G', 64, 64}, {"ec11", 'G', 64, 64},  {"ec12", 'G', 64, 64}, {"ec123", 'c', 192, 64},
+    {"dc1", 'G', 128, 64}, {"dc2", 'G', 64, 64},   {"dc22", 'c', 128, 64},
+    {"dc3", 'G', 128, 64}, {"dc4", 'G', 64, 32},   {"dc42", 'c', 96, 32},
+    {"dc5", 'g', 64, 32},  {"dc6", 'g', 32, 16},   {"dc62", 'c', 48, 16},
+};
+constexpr int kNumBlocks = sizeof(kBlocks) / sizeof(kBlocks[0]);
+
+struct ParamInfo { std::string name; int shape[5]; int ndim; };
+
+std::vector<ParamInfo> build_registry(const seunet_net_desc& d) {
+  std::vector<ParamInfo> r;
+  auto add5 = [&](const std::string& n, int a, int b, int k) { r.push_back({n, {a, b, k, k, k}, 5}); };
+  auto add1 = [&](const std::string& n, int a) { r.push_back({n, {a, 0, 0, 0, 0}, 1}); };
+  for (int i = 0; i < kNumBlocks; ++i) {
+    const BlockDesc& b = kBlocks[i];
+    const int ci = b.cin < 0 ? d.in_channel : b.cin * d.width_mult, co = b.cout * d.width_mult;
+    const std::string n = b.name;
+    if (b.kind == 'c') { add5(n + ".conv1.weight", co, ci, 1); continue; }
+    add5(n + ".conv1.weight", co, ci, 3);
+    add1(n + ".conv1.bias", co);
+    add5(n + ".conv2.weight", 2, co, 1);
+    add1(n + ".conv2.bias", 2);
+    add5(n + ".conv_se.weight", 1, co, 1);
+    if (b.kind == 'G') add5(n + ".conv_se2.weight", 1, co, 1);
+  }
+  add5("dc0_0.weight", d.n_classes, 24, 1);
+  add1("dc0_0.bias", d.n_classes);
+  add5("dc0_1.weight", d.n_classes, 12, 1);
+  add1("dc0_1.bias", d.n_classes);
+  return r;
+}
+
+int find_param(const std::vector<ParamInfo>& reg, const std::string& name) {
+  for (size_t i = 0; i < reg.size(); ++i)
+    if (reg[i].name == name) return (int)i;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the graph
+// ---------------------------------------------------------------------------------------------------
+enum TId {
+  T_X0, T_X1, T_X2,
+  T_E0, T_E1A, T_E1_1, T_E1, T_E2IN, T_E2, T_E3A, T_E3_1, T_E3, T_E4IN, T_E4, T_E5A, T_E5_1, T_E5,
+  T_E6IN, T_E6, T_E7A, T_E7_1, T_E7, T_E8, T_D0A, T_D0_1, T_D0, T_D1U, T_D1A, T_D1_1, T_D1, T_D2U, T_D2A, T_D2_1,
+  T_COUNT
+};
+struct TDesc { int level; int cbase; };  // cbase 0 = padded network input (8 channels)
+const TDesc kT[T_COUNT] = {
+    {0, 0}, {1, 0}, {2, 0},
+    {0, 8}, {0, 16}, {0, 32}, {0, 32}, {1, 32}, {1, 32}, {1, 32}, {1, 64}, {1, 64}, {2, 64}, {2, 64}, {2, 64}, {2, 64}, {2, 64},
+    {3, 64}, {3, 64}, {3, 64}, {3, 64}, {3, 64}, {2, 64}, {2, 64}, {2, 64}, {2, 64}, {1, 64}, {1, 64}, {1, 32}, {1, 32}, {0, 32}, {0, 32}, {0, 16},
+};
+
+enum OpKind { OP_GATED, OP_CAT, OP_POOL, OP_UP };
+struct OpDesc {
+  OpKind kind; const char* name; int nsrc; int src[3]; int dst;
+  int dil; int gates; int head; int m;   // gated: dilation, #gates, 0 = encoder head / 1 = decoder head, side slot
+  const char* xname; int xsrc;          // cat: optional raw-input branch
+};
+const OpDesc kOps[] = {
+    {OP_GATED, "ec1", 1, {T_X0, 0, 0}, T_E0, 1, 1, 0, 0, nullptr, 0},
+    {OP_GATED, "ec2", 1, {T_E0, 0, 0}, T_E1A, 1, 1, 0, 1, nullptr, 0},
+    {OP_GATED, "ec3", 1, {T_E1A, 0, 0}, T_E1_1, 2, 1, 0, 2, nullptr, 0},
+    {OP_CAT, "ec33", 3, {T_E1_1, T_E0, T_E1A}, T_E1, 0, 0, 0, 0, "x33", T_X0},
+    {OP_POOL, "pool0", 1, {T_E1, 0, 0}, T_E2IN, 0, 0, 0, 0, nullptr, 0},
+    {OP_POOL, "pool0x", 1, {T_X0, 0, 0}, T_X1, 0, 0, 0, 0, nullptr, 0},
+    {OP_GATED, "ec4", 1, {T_E2IN, 0, 0}, T_E2, 1, 2, 0, 3, nullptr, 0},
+    {OP_GATED, "ec5", 1, {T_E2, 0, 0}, T_E3A, 2, 2, 0, 4, nullptr, 0},
+    {OP_GATED, "ec6", 1, {T_E3A, 0, 0}, T_E3_1, 2, 2, 0, 5, nullptr, 0},
+    {OP_CAT, "ec63", 3, {T_E3_1, T_E2, T_E3A}, T_E3, 0, 0, 0, 0, "x63", T_X1},
+    {OP_POOL, "pool1", 1, {T_E3, 0, 0}, T_E4IN, 0, 0, 0, 0, nullptr, 0},
+    {OP_POOL, "pool1x", 1, {T_X1, 0, 0}, T_X2, 0, 0, 0, 0, nullptr, 0},
+    {OP_GATED, "ec7", 1, {T_E4IN, 0, 0}, T_E4, 1, 2, 0, 6, nullptr, 0},
+    {OP_GATED, "ec8", 1, {T_E4, 0, 0}, T_E5A, 2, 2, 0, 7, nullptr, 0},
+    {OP_GATED, "ec9", 1, {T_E5A, 0, 0}, T_E5_1, 2, 2, 0, 8, nullptr, 0},
+    {OP_CAT, "ec93", 3, {T_E5_1, T_E4, T_E5A}, T_E5, 0, 0, 0, 0, "x93", T_X2},
+    {OP_POOL, "pool2", 1, {T_E5, 0, 0}, T_E6IN, 0, 0, 0, 0, nullptr, 0},
+    {OP_GATED, "ec10", 1, {T_E6IN, 0, 0}, T_E6, 1, 2, 0, 9, nullptr, 0},
+    {OP_GATED, "ec11", 1, {T_E6, 0, 0}, T_E7A, 1, 2, 0, 10, nullptr, 0},
+    {OP_GATED, "ec12", 1, {T_E7A, 0, 0}, T_E7_1, 1, 2, 0, 11, nullptr, 0},
+    {OP_CAT, "ec123", 3, {T_E7_1, T_E6, T_E7A}, T_E7, 0, 0, 0, 0, nullptr, 0},
+    {OP_UP, "up0", 1, {T_E7, 0, 0}, T_E8, 0, 0, 0, 0, nullptr, 0},
+    {OP_GATED, "dc1", 2, {T_E8, T_E5, 0}, T_D0A, 1, 2, 1, 0, nullptr, 0},
+    {OP_GATED, "dc2", 1, {T_D0A, 0, 0}, T_D0_1, 1, 2, 1, 1, nullptr, 0},
+    {OP_CAT, "dc22", 2, {T_D0_1, T_D0A, 0}, T_D0, 0, 0, 0, 0, nullptr, 0},
+    {OP_UP, "up1", 1, {T_D0, 0, 0}, T_D1U, 0, 0, 0, 0, nullptr, 0},
+    {OP_GATED, "dc3", 2, {T_D1U, T_E3, 0}, T_D1A, 1, 2, 1, 2, nullptr, 0},
+    {OP_GATED, "dc4", 1, {T_D1A, 0, 0}, T_D1_1, 1, 2, 1, 3, nullptr, 0},
+    {OP_CAT, "dc42", 2, {T_D1_1, T_D1A, 0}, T_D1, 0, 0, 0, 0, nullptr, 0},
+    {OP_UP, "up2", 1, {T_D1, 0, 0}, T_D2U, 0, 0, 0, 0, nullptr, 0},
+    {OP_GATED, "dc5", 2, {T_D2U, T_E1, 0}, T_D2A, 1, 1, 1, 4, nullptr, 0},
+    {OP_GATED, "dc6", 1, {T_D2A, 0, 0}, T_D2_1, 1, 1, 1, 5, nullptr, 0},
+    // dc62 (SE_UNet.py:148,230) is dead: never evaluated, no gradient
+};
+constexpr int kNumOps = sizeof(kOps) / sizeof(kOps[0]);
+
+inline bool is_input(int t) { return t <= T_X2; }
+
+// ---------------------------------------------------------------------------------------------------
+// workspace plan
+// ---------------------------------------------------------------------------------------------------
+struct OpRes {
+  size_t raw = 0, raw2 = 0, mean = 0, rstd = 0, mean2 = 0, rstd2 = 0, wp_f = 0, wp_d = 0, wp_x = 0;
+  int cin = 0, cout = 0, taps = 0;
+  bool need_dgrad = false;
+};
+
+struct Plan {
+  seunet_net_desc d;
+  size_t esz;
+  Dims dims[4];
+  int C[T_COUNT];
+  size_t feat[T_COUNT], grad[T_COUNT];
+  OpRes op[kNumOps];
+  size_t lvl[2][4], glvl[2][4];
+  size_t stats, stats2, pgrad, m1, m2, m1b, m2b, wgrad_ws, head_tmp, gx;
+  size_t wgrad_ws_bytes;
+  size_t total;
+  int stat_slots_max;
+
+  size_t cur = 0;
+  size_t take(size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; }
+
+  int init(const seunet_net_desc& desc) {
+    d = desc;
+    SEUNET_CHECK(d.batch >= 1 && d.in_channel >= 1 && d.in_channel <= 8, "net: batch/in_channel out of range");
+    SEUNET_CHECK(d.n_classes == 1, "net: n_classes=%d is not implemented in the HIP path (reference callers use 1)", d.n_classes);
+    SEUNET_CHECK(d.d % 8 == 0 && d.h % 8 == 0 && d.w % 8 == 0 && d.d >= 8 && d.h >= 8 && d.w >= 8,
+                 "net: spatial extents (%d,%d,%d) must be multiples of 8", d.d, d.h, d.w);
+    SEUNET_CHECK(d.width_mult == 1 || d.width_mult == 2, "net: width_mult %d unsupported (1 or 2)", d.width_mult);
+    SEUNET_CHECK(d.dtype == SEUNET_F32 || d.dtype == SEUNET_BF16, "net: dtype %d unsupported", d.dtype);
+    esz = dtype_size(d.dtype);
+    for (int l = 0; l < 4; ++l) dims[l] = Dims{d.batch, d.d >> l, d.h >> l, d.w >> l};
+    for (int t = 0; t < T_COUNT; ++t) C[t] = kT[t].cbase == 0 ? 8 : kT[t].cbase * d.width_mult;
+    for (int t = 0; t < T_COUNT; ++t) {
+      const size_t bytes = (size_t)d.batch * dims[kT[t].level].vox() * C[t] * esz;
+      feat[t] = take(bytes);
+      grad[t] = is_input(t) ? 0 : take(bytes);
+    }
+    size_t gx_max = 0, wg_max = 0;
+    int slots_max = 1, cmax = 8;
+    for (int i = 0; i < kNumOps; ++i) {
+      const OpDesc& o = kOps[i];
+      OpRes& r = op[i];
+      if (o.kind == OP_POOL || o.kind == OP_UP) continue;
+      const int lv = kT[o.dst].level;
+      r.cout = C[o.dst];
+      r.taps = o.kind == OP_GATED ? 27 : 1;
+      int cin = 0;
+      bool any_grad = false;
+      for (int k = 0; k < o.nsrc; ++k) { cin += C[o.src[k]]; any_grad |= !is_input(o.src[k]); }
+      if (o.nsrc == 1 && is_input(o.src[0])) cin = d.in_channel;
+      r.cin = cin;
+      r.need_dgrad = any_grad;
+      const size_t act = (size_t)d.batch * dims[lv].vox() * r.cout * esz;
+      r.raw = take(act);
+      r.mean = take((size_t)d.batch * r.cout * 4);
+      r.rstd = take((size_t)d.batch * r.cout * 4);
+      r.wp_f = take(conv_wpack_bytes(d.dtype, r.taps, r.cin, r.cout));
+      if (r.need_dgrad) r.wp_d = take(conv_wpack_bytes(d.dtype, r.taps, r.cout, r.cin));
+      wg_max = std::max(wg_max, wgrad_workspace_bytes(r.taps, r.cin, r.cout));
+      if (o.xname) {
+        r.raw2 = take(act);
+        r.mean2 = take((size_t)d.batch * r.cout * 4);
+        r.rstd2 = take((size_t)d.batch * r.cout * 4);
+        r.wp_x = take(conv_wpack_bytes(d.dtype, 1, d.in_channel, r.cout));
+        gx_max = std::max(gx_max, act);
+        wg_max = std::max(wg_max, wgrad_workspace_bytes(1, d.in_channel, r.cout));
+      }
+      slots_max = std::max(slots_max, std::max(conv_stats_tiles(dims[lv]), epi_partials(dims[lv])));
+      cmax = std::max(cmax, r.cout);
+    }
+    stat_slots_max = slots_max;
+    for (int h = 0; h < 2; ++h)
+      for (int l = 0; l < 4; ++l) {
+        lvl[h][l] = take((size_t)d.batch * dims[l].vox() * 4);
+        glvl[h][l] = take((size_t)d.batch * dims[l].vox() * 4);
+      }
+    const size_t stat_bytes = (size_t)d.batch * slots_max * cmax * 2 * 4;
+    stats = take(stat_bytes);
+    stats2 = take(stat_bytes);
+    pgrad = take((size_t)d.batch * slots_max * (4 * cmax + 4) * 4);
+    m1 = take((size_t)d.batch * cmax * 4);
+    m2 = take((size_t)d.batch * cmax * 4);
+    m1b = take((size_t)d.batch * cmax * 4);
+    m2b = take((size_t)d.batch * cmax * 4);
+    wgrad_ws_bytes = wg_max;
+    wgrad_ws = take(wg_max);
+    head_tmp = take(head_bwd_tmp_floats(dims[0]) * 4);
+    gx = take(gx_max);
+    total = cur;
+    return 0;
+  }
+};
+
+struct Exec {
+  Plan p;
+  std::vector<ParamInfo> reg;
+  unsigned char* ws = nullptr;
+  const float* const* params = nullptr;
+  hipStream_t s = nullptr;
+
+  void* at(size_t off) const { return ws + off; }
+  float* fat(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+  const float* P(const std::string& name) const {
+    const int i = find_param(reg, name);
+    return i < 0 ? nullptr : params[i];
+  }
+
+  int setup(const seunet_net_desc* desc, const float* const* prm, void* workspace, size_t bytes, hipStream_t st) {
+    SEUNET_CHECK(desc && prm && workspace, "net: null argument");
+    if (int e = p.init(*desc)) return e;
+    SEUNET_CHECK(bytes >= p.total, "net: workspace too small (%zu < %zu bytes)", bytes, p.total);
+    SEUNET_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "net: workspace must be 256-byte aligned");
+    reg = build_registry(p.d);
+    ws = reinterpret_cast<unsigned char*>(workspace);
+    params = prm;
+    s = st;
+    for (size_t i = 0; i < reg.size(); ++i)
+      SEUNET_CHECK(prm[i] != nullptr || reg[i].name.rfind("dc62", 0) == 0, "net: parameter %s is null", reg[i].name.c_str());
+    return 0;
+  }
+
+  SrcList srcs(const OpDesc& o) const {
+    SrcList l{};
+    l.n = o.nsrc;
+    for (int k = 0; k < o.nsrc; ++k) { l.ptr[k] = at(p.feat[o.src[k]]); l.C[k] = p.C[o.src[k]]; }
+    return l;
+  }
+
+  // conv (+ InstanceNorm statistics) of one block: raw <- conv(src), (mean, rstd) <- stats(raw)
+  int conv_and_stats(int taps, int dil, const SrcList& src, int cin, const float* w, const float* bias, size_t wp_off,
+                     size_t raw_off, int cout, size_t mean_off, size_t rstd_off, const Dims& dm) {
+    DstList dst{};
+    dst.n = 1; dst.ptr[0] = at(raw_off); dst.C[0] = cout; dst.acc[0] = 0;
+    int slots;
+    if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
+      if (int e = launch_conv_naive(p.d.dtype, taps, dil, src, cin, w, 0, bias, dst, dm, s)) return e;
+      if (int e = launch_channel_stats(p.d.dtype, at(raw_off), cout, fat(p.stats), dm, s)) return e;
+      slots = epi_partials(dm);
+    } else {
+      if (int e = launch_conv_pack_weights(p.d.dtype, w, taps, cin, cout, 0, at(wp_off), s)) return e;
+      if (int e = launch_conv_igemm(p.d.dtype, taps, dil, src, cin, at(wp_off), bias, dst, fat(p.stats), dm, s)) return e;
+      slots = conv_stats_tiles(dm);
+    }
+    return launch_stats_finalize(fat(p.stats), slots, cout, dm.N, dm.vox(), p.d.eps, 0, fat(mean_off), fat(rstd_off), s);
+  }
+
+  SseParams sse_params(const OpDesc& o) const {
+    const std::string n = o.name;
+    SseParams sp{};
+    sp.w_se = P(n + ".conv_se.weight");
+    sp.w_se2 = o.gates == 2 ? P(n + ".conv_se2.weight") : nullptr;
+    sp.w_side = P(n + ".conv2.weight");
+    sp.b_side = P(n + ".conv2.bias");
+    sp.slope = p.d.negative_slope;
+    return sp;
+  }
+  SseHead sse_head(const OpDesc& o, const float* drop1, const float* drop2, bool first_of_level) const {
+    SseHead h{};
+    const int lv = kT[o.dst].level;
+    h.side_out = nullptr;
+    h.level_map = fat(p.lvl[o.head][lv]);
+    h.level_accumulate = first_of_level ? 0 : 1;
+    h.head_w = (o.head == 0 ? P("dc0_0.weight") : P("dc0_1.weight")) + 2 * o.m;
+    const float* dr = o.head == 0 ? drop1 : drop2;
+    h.drop = dr ? dr + 2 * o.m : nullptr;
+    h.drop_stride = o.head == 0 ? 24 : 12;
+    return h;
+  }
+
+  int forward(const float* x, const float* drop1, const float* drop2, float* pred0, float* pred1) {
+    if (int e = launch_pack_input(p.d.dtype, x, p.d.in_channel, at(p.feat[T_X0]), p.dims[0], s)) return e;
+    bool lvl_written[2][4] = {{false, false, false, false}, {false, false, false, false}};
+    for (int i = 0; i < kNumOps; ++i) {
+      const OpDesc& o = kOps[i];
+      const OpRes& r = p.op[i];
+      const std::string n = o.name;
+      if (o.kind == OP_POOL) {
+        if (int e = launch_maxpool_fwd(p.d.dtype, at(p.feat[o.src[0]]), p.C[o.src[0]], at(p.feat[o.dst]), p.dims[kT[o.src[0]].level], s)) return e;
+      } else if (o.kind == OP_UP) {
+        if (int e = launch_upsample2_fwd(p.d.dtype, at(p.feat[o.src[0]]), p.C[o.src[0]], at(p.feat[o.dst]), p.dims[kT[o.src[0]].level], s)) return e;
+      } else if (o.kind == OP_GATED) {
+        const int lv = kT[o.dst].level;
+        if (int e = conv_and_stats(27, o.dil, srcs(o), r.cin, P(n + ".conv1.weight"), P(n + ".conv1.bias"), r.wp_f, r.raw,
+                                   r.cout, r.mean, r.rstd, p.dims[lv])) return e;
+        const SseHead hd = sse_head(o, drop1, drop2, !lvl_written[o.head][lv]);
+        lvl_written[o.head][lv] = true;
+        if (int e = launch_sse_fwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), at(p.feat[o.dst]), hd,
+                                   p.dims[lv], s)) return e;
+      } else {  // OP_CAT
+        const int lv = kT[o.dst].level;
+        if (int e = conv_and_stats(1, 1, srcs(o), r.cin, P(n + ".conv1.weight"), nullptr, r.wp_f, r.raw, r.cout, r.mean,
+                                   r.rstd, p.dims[lv])) return e;
+        if (o.xname) {
+          SrcList xs{};
+          xs.n = 1; xs.ptr[0] = at(p.feat[o.xsrc]); xs.C[0] = 8;
+          if (int e = conv_and_stats(1, 1, xs, p.d.in_channel, P(std::string(o.xname) + ".conv1.weight"), nullptr, r.wp_x,
+                                     r.raw2, r.cout, r.mean2, r.rstd2, p.dims[lv])) return e;
+        }
+        if (int e = launch_cat_fwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), o.xname ? at(r.raw2) : nullptr,
+                                   o.xname ? fat(r.mean2) : nullptr, o.xname ? fat(r.rstd2) : nullptr, r.cout,
+                                   p.d.negative_slope, at(p.feat[o.dst]), p.dims[lv], s)) return e;
+      }
+    }
+    const float* enc[4] = {fat(p.lvl[0][0]), fat(p.lvl[0][1]), fat(p.lvl[0][2]), fat(p.lvl[0][3])};
+    const float* dec[3] = {fat(p.lvl[1][0]), fat(p.lvl[1][1]), fat(p.lvl[1][2])};
+    if (int e = launch_head_fwd(enc, 4, P("dc0_0.bias"), pred0, p.dims[0], s)) return e;
+    return launch_head_fwd(dec, 3, P("dc0_1.bias"), pred1, p.dims[0], s);
+  }
+
+  // gradient w.r.t. the raw conv output is in grad[dst]; produce weight gradient and input gradients
+  int conv_backward(int i, const SrcList& x, float* const* grads, bool* written) {
+    const OpDesc& o = kOps[i];
+    const OpRes& r = p.op[i];
+    const int lv = kT[o.dst].level;
+    const std::string n = o.name;
+    const int wi = find_param(reg, n + ".conv1.weight");
+    if (grads[wi]) {
+      if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
+        if (int e = launch_wgrad_naive(p.d.dtype, r.taps, o.dil, x, r.cin, at(p.grad[o.dst]), r.cout, grads[wi], p.dims[lv], s)) return e;
+      } else {
+        if (int e = launch_wgrad(p.d.dtype, r.taps, o.dil, x, r.cin, at(p.grad[o.dst]), r.cout, grads[wi], at(p.wgrad_ws),
+                                 p.wgrad_ws_bytes, p.dims[lv], s)) return e;
+      }
+    }
+    if (!r.need_dgrad) return 0;
+    SrcList gsrc{};
+    gsrc.n = 1; gsrc.ptr[0] = at(p.grad[o.dst]); gsrc.C[0] = r.cout;
+    DstList gd{};
+    gd.n = o.nsrc;
+    for (int k = 0; k < o.nsrc; ++k) {
+      const int t = o.src[k];
+      gd.C[k] = p.C[t];
+      gd.ptr[k] = is_input(t) ? nullptr : at(p.grad[t]);
+      gd.acc[k] = (!is_input(t) && written[t]) ? 1 : 0;
+      if (!is_input(t)) written[t] = true;
+    }
+    const float* w = P(n + ".conv1.weight");
+    if (p.d.conv_impl == SEUNET_CONV_NAIVE)
+      return launch_conv_naive(p.d.dtype, r.taps, o.dil, gsrc, r.cout, w, 1, nullptr, gd, p.dims[lv], s);
+    if (int e = launch_conv_pack_weights(p.d.dtype, w, r.taps, r.cin, r.cout, 1, at(r.wp_d), s)) return e;
+    return launch_conv_igemm(p.d.dtype, r.taps, o.dil, gsrc, r.cout, at(r.wp_d), nullptr, gd, nullptr, p.dims[lv], s);
+  }
+
+  int backward(const float* g_pred0, const float* g_pred1, const float* drop1, const float* drop2, float* const* grads) {
+    bool written[T_COUNT];
+    for (int t = 0; t < T_COUNT; ++t) written[t] = false;
+    // heads: level gradients = transposed interpolation of the logit gradients
+    {
+      float* ge[4] = {nullptr, fat(p.glvl[0][1]), fat(p.glvl[0][2]), fat(p.glvl[0][3])};
+      float* gd[4] = {nullptr, fat(p.glvl[1][1]), fat(p.glvl[1][2]), nullptr};
+      if (int e = launch_head_bwd(g_pred0, ge, 4, fat(p.head_tmp), grads[find_param(reg, "dc0_0.bias")], p.dims[0], s)) return e;
+      if (int e = launch_head_bwd(g_pred1, gd, 3, fat(p.head_tmp), grads[find_param(reg, "dc0_1.bias")], p.dims[0], s)) return e;
+    }
+    for (int i = kNumOps - 1; i >= 0; --i) {
+      const OpDesc& o = kOps[i];
+      const OpRes& r = p.op[i];
+      const std::string n = o.name;
+      if (o.kind == OP_POOL || o.kind == OP_UP) {
+        const int t = o.src[0];
+        if (is_input(t)) continue;
+        SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
+        if (o.kind == OP_POOL) {
+          if (int e = launch_maxpool_bwd(p.d.dtype, at(p.feat[t]), at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
+                                         p.dims[kT[t].level], s)) return e;
+        } else {
+          if (int e = launch_upsample2_bwd(p.d.dtype, at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
+                                           p.dims[kT[t].level], s)) return e;
+        }
+        written[t] = true;
+        continue;
+      }
+      const int lv = kT[o.dst].level;
+      const Dims& dm = p.dims[lv];
+      const int P_slots = epi_partials(dm);
+      if (o.kind == OP_GATED) {
+        SseBwdIn g{};
+        g.g_e = written[o.dst] ? at(p.grad[o.dst]) : nullptr;
+        g.g_side = nullptr;
+        g.g_level = lv == 0 ? (o.head == 0 ? g_pred0 : g_pred1) : fat(p.glvl[o.head][lv]);
+        const SseHead hd = sse_head(o, drop1, drop2, false);
+        if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd,
+                                   at(p.grad[o.dst]), fat(p.stats), fat(p.pgrad), dm, s)) return e;
+        written[o.dst] = true;
+        if (int e = launch_stats_finalize(fat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
+        float* g_head = grads[find_param(reg, o.head == 0 ? "dc0_0.weight" : "dc0_1.weight")];
+        const int i_se2 = o.gates == 2 ? find_param(reg, n + ".conv_se2.weight") : -1;
+        if (int e = launch_pgrad_reduce(fat(p.pgrad), dm.N * P_slots, r.cout, grads[find_param(reg, n + ".conv_se.weight")],
+                                        i_se2 >= 0 ? grads[i_se2] : nullptr, grads[find_param(reg, n + ".conv2.weight")],
+                                        grads[find_param(reg, n + ".conv2.bias")], g_head ? g_head + 2 * o.m : nullptr, s)) return e;
+        if (int e = launch_in_bwd_apply(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), fat(p.m1), fat(p.m2),
+                                        r.cout, dm, s)) return e;
+        // conv1.bias feeds an affine-less InstanceNorm: its gradient is identically zero
+        if (float* gb = grads[find_param(reg, n + ".conv1.bias")]) SEUNET_HIP(hipMemsetAsync(gb, 0, (size_t)r.cout * 4, s));
+        if (int e = conv_backward(i, srcs(o), grads, written)) return e;
+      } else {  // OP_CAT
+        SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
+        if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), o.xname ? at(r.raw2) : nullptr,
+                                   o.xname ? fat(r.mean2) : nullptr, o.xname ? fat(r.rstd2) : nullptr, r.cout, p.d.negative_slope,
+                                   at(p.grad[o.dst]), o.xname ? at(p.gx) : nullptr, fat(p.stats), fat(p.stats2), dm, s)) return e;
+        if (int e = launch_stats_finalize(fat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
+        if (int e = launch_in_bwd_apply(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), fat(p.m1), fat(p.m2),
+                                        r.cout, dm, s)) return e;
+        if (o.xname) {
+          if (int e = launch_stats_finalize(fat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
+          if (int e = launch_in_bwd_apply(p.d.dtype, at(p.gx), at(r.raw2), fat(r.mean2), fat(r.rstd2), fat(p.m1b), fat(p.m2b),
+                                          r.cout, dm, s)) return e;
+          const int xi = find_param(reg, std::string(o.xname) + ".conv1.weight");
+          if (grads[xi]) {
+            SrcList xs{};
+            xs.n = 1; xs.ptr[0] = at(p.feat[o.xsrc]); xs.C[0] = 8;
+            if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
+              if (int e = launch_wgrad_naive(p.d.dtype, 1, 1, xs, p.d.in_channel, at(p.gx), r.cout, grads[xi], dm, s)) return e;
+            } else {
+              if (int e = launch_wgrad(p.d.dtype, 1, 1, xs, p.d.in_channel, at(p.gx), r.cout, grads[xi], at(p.wgrad_ws),
+                                       p.wgrad_ws_bytes, dm, s)) return e;
+            }
+          }
+        }
+        if (int e = conv_backward(i, srcs(o), grads, written)) return e;
+      }
+    }
+    return 0;
+  }
+};
+
+}  // namespace
+}  // namespace seunet
+
+using namespace seunet;
+
+extern "C" {
+
+int seunet_net_param_count(const seunet_net_desc* desc) {
+  if (!desc) return -1;
+  return (int)build_registry(*desc).size();
+}
+
+int seunet_net_param_info(const seunet_net_desc* desc, int index, char* name, int name_cap, int* shape5, int* ndim) {
+  SEUNET_CHECK(desc && name && shape5 && ndim, "param_info: null argument");
+  const std::vector<ParamInfo> reg = build_registry(*desc);
+  SEUNET_CHECK(index >= 0 && index < (int)reg.size(), "param_info: index %d out of range", index);
+  snprintf(name, (size_t)name_cap, "%s", reg[index].name.c_str());
+  for (int k = 0; k < 5; ++k) shape5[k] = reg[index].shape[k];
+  *ndim = reg[index].ndim;
+  return 0;
+}
+
+size_t seunet_net_workspace_bytes(const seunet_net_desc* desc) {
+  if (!desc) return 0;
+  Plan p;
+  if (p.init(*desc)) return 0;
+  return p.total;
+}
+
+int seunet_net_forward(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
+                       const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
+                       seunet_stream_t s) {
+  SEUNET_CHECK(x && pred0 && pred1, "net_forward: null tensor");
+  Exec ex;
+  if (int e = ex.setup(desc, params, workspace, workspace_bytes, (hipStream_t)s)) return e;
+  return ex.forward(x, drop1, drop2, pred0, pred1);
+}
+
+int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
+                        const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
+                        void* workspace, size_t workspace_bytes, seunet_stream_t s) {
+  SEUNET_CHECK(g_pred0 && g_pred1 && grads, "net_backward: null tensor");
+  Exec ex;
+  if (int e = ex.setup(desc, params, workspace, workspace_bytes, (hipStream_t)s)) return e;
+  return ex.backward(g_pred0, g_pred1, drop1, drop2, grads);
+}
+
+}  // extern "C"

@@ -1,0 +1,462 @@
+// Layout conversion, 2x2x2 max-pool, trilinear (align_corners=True) up-sampling and the two
+// deep-supervision heads (gfx950).  All HBM-bound; one lane moves 8 channels (16/32 B).
+//
+//   max-pool      reference SE_UNet.py:131-133 (nn.MaxPool3d 2/2)
+//   up-sampling   reference SE_UNet.py:136-138 (nn.Upsample x2 trilinear align_corners=True) and
+//                 the per-block side-map up-sampling by 1/2/4/8 (SE_UNet.py:19,34,61,81)
+//   heads         reference SE_UNet.py:150-153,232-233: 1x1x1 conv over the DropLayer-scaled stack of
+//                 up-sampled side maps.  Both are linear, so the head weight and the DropLayer scale
+//                 are applied to each side map at its native resolution (epilogue.hip accumulates a
+//                 single-channel "level map" per resolution) and only those maps are interpolated.
+#include "seunet_common.h"
+
+namespace seunet {
+
+// ---------------- trilinear index helpers (PyTorch align_corners=True semantics) -------------
+__device__ __forceinline__ float ac_scale(int in, int out) {
+  return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+}
+__device__ __forceinline__ void ac_src(int o, float rs, int in, int& i0, int& i1, float& lam) {
+  const float src = rs * (float)o;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+// output indices that can touch input index i
+__device__ __forceinline__ void ac_range(int i, float rs, int out, int& lo, int& hi) {
+  if (rs <= 0.f) { lo = 0; hi = out - 1; return; }
+  lo = (int)floorf((float)(i - 1) / rs) - 1;
+  hi = (int)ceilf((float)(i + 1) / rs) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+__device__ __forceinline__ float ac_weight(int o, int i, float rs, int in) {
+  int i0, i1; float lam;
+  ac_src(o, rs, in, i0, i1, lam);
+  return (i0 == i ? 1.f - lam : 0.f) + (i1 == i ? lam : 0.f);
+}
+
+// ---------------- layout ---------------------------------------------------------------------
+template <typename T>
+__global__ void pack_cl_kernel(const float* __restrict__ in, int C, T* __restrict__ out, int Cpad,
+                               long long V, long long total) {
+  // thread -> (n, group, v) with v fastest: coalesced f32 reads per channel plane
+  const int G = Cpad / 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long v = i % V;
+    const int g = (int)((i / V) % G);
+    const long long n = i / (V * G);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g * 8 + j;
+      x[j] = c < C ? in[(n * C + c) * V + v] : 0.f;
+    }
+    store8(out + (n * V + v) * Cpad + g * 8, x);
+  }
+}
+
+template <typename T>
+__global__ void unpack_cl_kernel(const T* __restrict__ in, int C, float* __restrict__ out, long long V,
+                                 long long total) {
+  const int G = C / 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long v = i % V;
+    const int g = (int)((i / V) % G);
+    const long long n = i / (V * G);
+    float x[8];
+    load8(in + (n * V + v) * C + g * 8, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[(n * C + g * 8 + j) * V + v] = x[j];
+  }
+}
+
+// ---------------- max-pool 2x2x2 ---------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ in, int C, T* __restrict__ out, int D, int H,
+                                   int W, long long total) {
+  const int G = C / 8, Do = D / 2, Ho = H / 2, Wo = W / 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const long long n = r / Do;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), x = 2 * xo + (k & 1);
+      float v[8];
+      load8(in + ((((n * D + z) * H + y) * W + x) * (long long)C) + g * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+    }
+    store8(out + ((((n * Do + zo) * Ho + yo) * Wo + xo) * (long long)C) + g * 8, m);
+  }
+}
+
+// routes g_out to the FIRST maximum of each window in (z,y,x) scan order (PyTorch CPU semantics)
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ in, const T* __restrict__ g_out, int C,
+                                   T* g_in, int accumulate, int D, int H, int W, long long total) {
+  const int G = C / 8, Do = D / 2, Ho = H / 2, Wo = W / 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const long long n = r / Do;
+    float m[8], gy[8];
+    int am[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = 0; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), x = 2 * xo + (k & 1);
+      float v[8];
+      load8(in + ((((n * D + z) * H + y) * W + x) * (long long)C) + g * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (v[j] > m[j]) { m[j] = v[j]; am[j] = k; }
+    }
+    load8(g_out + ((((n * Do + zo) * Ho + yo) * Wo + xo) * (long long)C) + g * 8, gy);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), x = 2 * xo + (k & 1);
+      T* p = g_in + ((((n * D + z) * H + y) * W + x) * (long long)C) + g * 8;
+      float v[8];
+      if (accumulate) load8(p, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (accumulate ? v[j] : 0.f) + (am[j] == k ? gy[j] : 0.f);
+      store8(p, v);
+    }
+  }
+}
+
+// ---------------- x2 trilinear up-sampling of feature maps ------------------------------------
+template <typename T>
+__global__ void upsample2_fwd_kernel(const T* __restrict__ in, int C, T* __restrict__ out, int D, int H,
+                                     int W, long long total) {
+  const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const long long n = r / Do;
+    int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+    ac_src(zo, rz, D, z0, z1, lz);
+    ac_src(yo, ry, H, y0, y1, ly);
+    ac_src(xo, rx, W, x0, x1, lx);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = (k & 4) ? z1 : z0, y = (k & 2) ? y1 : y0, x = (k & 1) ? x1 : x0;
+      const float w = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+      float v[8];
+      load8(in + ((((n * D + z) * H + y) * W + x) * (long long)C) + g * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+    }
+    store8(out + ((((n * Do + zo) * Ho + yo) * Wo + xo) * (long long)C) + g * 8, acc);
+  }
+}
+
+// gather form of the transposed interpolation: one lane per (input voxel, 8 channels)
+template <typename T>
+__global__ void upsample2_bwd_kernel(const T* __restrict__ g_out, int C, T* g_in, int accumulate, int D,
+                                     int H, int W, long long total) {
+  const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H); r /= H;
+    const int z = (int)(r % D);
+    const long long n = r / D;
+    int zl, zh, yl, yh, xl, xh;
+    ac_range(z, rz, Do, zl, zh);
+    ac_range(y, ry, Ho, yl, yh);
+    ac_range(x, rx, Wo, xl, xh);
+    float acc[8];
+    T* p = g_in + ((((n * D + z) * H + y) * W + x) * (long long)C) + g * 8;
+    if (accumulate) load8(p, acc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    }
+    for (int zo = zl; zo <= zh; ++zo) {
+      const float wz = ac_weight(zo, z, rz, D);
+      if (wz == 0.f) continue;
+      for (int yo = yl; yo <= yh; ++yo) {
+        const float wy = ac_weight(yo, y, ry, H);
+        if (wy == 0.f) continue;
+        for (int xo = xl; xo <= xh; ++xo) {
+          const float wx = ac_weight(xo, x, rx, W);
+          if (wx == 0.f) continue;
+          float v[8];
+          load8(g_out + ((((n * Do + zo) * Ho + yo) * Wo + xo) * (long long)C) + g * 8, v);
+          const float w = wz * wy * wx;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+        }
+      }
+    }
+    store8(p, acc);
+  }
+}
+
+// ---------------- side map up-sampling to NCDHW (block-level API / tests only) ------------------
+__global__ void side_upsample_kernel(const float* __restrict__ side, int C, int scale,
+                                     float* __restrict__ out, int c_total, int c_off, int D, int H, int W,
+                                     long long total) {
+  const int Do = D * scale, Ho = H * scale, Wo = W * scale;
+  const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
+  const long long Vo = (long long)Do * Ho * Wo;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const long long n = r / Do;
+    int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+    ac_src(zo, rz, D, z0, z1, lz);
+    ac_src(yo, ry, H, y0, y1, ly);
+    ac_src(xo, rx, W, x0, x1, lx);
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int z = (k & 4) ? z1 : z0, y = (k & 2) ? y1 : y0, x = (k & 1) ? x1 : x0;
+        const float w = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+        acc += w * side[((((n * D + z) * H + y) * W + x) * (long long)C) + c];
+      }
+      out[(n * c_total + c_off + c) * Vo + (((long long)zo * Ho + yo) * Wo + xo)] = acc;
+    }
+  }
+}
+
+// ---------------- heads ---------------------------------------------------------------------------
+struct HeadLevels {
+  const float* map[4];  // level l has extents (D0>>l, H0>>l, W0>>l); null = level absent
+};
+
+__global__ void head_fwd_kernel(HeadLevels lv, const float* __restrict__ bias, float* __restrict__ pred,
+                                int D, int H, int W, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int xo = (int)(r % W); r /= W;
+    const int yo = (int)(r % H); r /= H;
+    const int zo = (int)(r % D);
+    const long long n = r / D;
+    float acc = bias[0];
+    if (lv.map[0]) acc += lv.map[0][i];
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+      if (!lv.map[l]) continue;
+      const int Dl = D >> l, Hl = H >> l, Wl = W >> l;
+      int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+      ac_src(zo, ac_scale(Dl, D), Dl, z0, z1, lz);
+      ac_src(yo, ac_scale(Hl, H), Hl, y0, y1, ly);
+      ac_src(xo, ac_scale(Wl, W), Wl, x0, x1, lx);
+      const float* m = lv.map[l] + n * (long long)Dl * Hl * Wl;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int z = (k & 4) ? z1 : z0, y = (k & 2) ? y1 : y0, x = (k & 1) ? x1 : x0;
+        const float w = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+        a += w * m[((long long)z * Hl + y) * Wl + x];
+      }
+      acc += a;
+    }
+    pred[i] = acc;
+  }
+}
+
+// transposed 1-D interpolation along one axis of an f32 tensor viewed as [outer][O][inner] -> [outer][I][inner]
+__global__ void up_transpose_axis_kernel(const float* __restrict__ in, float* __restrict__ out, int I, int O,
+                                         long long inner, long long total) {
+  const float rs = ac_scale(I, O);
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long in_i = idx % inner;
+    const int i = (int)((idx / inner) % I);
+    const long long outer = idx / (inner * I);
+    int lo, hi;
+    ac_range(i, rs, O, lo, hi);
+    float acc = 0.f;
+    for (int o = lo; o <= hi; ++o) {
+      const float w = ac_weight(o, i, rs, I);
+      if (w != 0.f) acc += w * in[(outer * O + o) * inner + in_i];
+    }
+    out[idx] = acc;
+  }
+}
+
+// deterministic two-stage sum of an f32 array
+__global__ void __launch_bounds__(256) sum_stage1_kernel(const float* __restrict__ in, long long n,
+                                                         double* __restrict__ partial) {
+  double s = 0.0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)in[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((w[0] + w[1]) + w[2]) + w[3];
+}
+__global__ void sum_stage2_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    out[0] = (float)s;
+  }
+}
+
+// ---------------- launchers -----------------------------------------------------------------------
+static inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int launch_pack_cl(int dtype, const float* in, int C, void* out, int Cpad, Dims d, hipStream_t s) {
+  SEUNET_CHECK(Cpad % 8 == 0 && Cpad >= C, "pack_cl: padded channel count %d invalid for C=%d", Cpad, C);
+  const long long V = d.vox(), total = (long long)d.N * V * (Cpad / 8);
+  if (dtype == SEUNET_BF16)
+    pack_cl_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>(in, C, (bf16_t*)out, Cpad, V, total);
+  else
+    pack_cl_kernel<float><<<grid_for(total), 256, 0, s>>>(in, C, (float*)out, Cpad, V, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+int launch_pack_input(int dtype, const float* x, int in_channel, void* out, Dims d, hipStream_t s) {
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 8, "in_channel %d unsupported (1..8)", in_channel);
+  return launch_pack_cl(dtype, x, in_channel, out, 8, d, s);
+}
+int launch_unpack_cl(int dtype, const void* in, int C, float* out, Dims d, hipStream_t s) {
+  SEUNET_CHECK(C % 8 == 0, "unpack_cl: C=%d must be a multiple of 8", C);
+  const long long V = d.vox(), total = (long long)d.N * V * (C / 8);
+  if (dtype == SEUNET_BF16)
+    unpack_cl_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, C, out, V, total);
+  else
+    unpack_cl_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, C, out, V, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims d, hipStream_t s) {
+  SEUNET_CHECK(C % 8 == 0 && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0, "maxpool: bad shape");
+  const long long total = (long long)d.N * (d.D / 2) * (d.H / 2) * (d.W / 2) * (C / 8);
+  if (dtype == SEUNET_BF16)
+    maxpool_fwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, C, (bf16_t*)out, d.D, d.H, d.W, total);
+  else
+    maxpool_fwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, C, (float*)out, d.D, d.H, d.W, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void* g_in, int accumulate,
+                       Dims d, hipStream_t s) {
+  SEUNET_CHECK(C % 8 == 0 && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0, "maxpool: bad shape");
+  const long long total = (long long)d.N * (d.D / 2) * (d.H / 2) * (d.W / 2) * (C / 8);
+  if (dtype == SEUNET_BF16)
+    maxpool_bwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, (const bf16_t*)g_out, C, (bf16_t*)g_in, accumulate, d.D, d.H, d.W, total);
+  else
+    maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, (const float*)g_out, C, (float*)g_in, accumulate, d.D, d.H, d.W, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims d, hipStream_t s) {
+  SEUNET_CHECK(C % 8 == 0, "upsample2: C=%d must be a multiple of 8", C);
+  const long long total = (long long)d.N * d.vox() * 8 * (C / 8);
+  if (dtype == SEUNET_BF16)
+    upsample2_fwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, C, (bf16_t*)out, d.D, d.H, d.W, total);
+  else
+    upsample2_fwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, C, (float*)out, d.D, d.H, d.W, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate, Dims d,
+                         hipStream_t s) {
+  SEUNET_CHECK(C % 8 == 0, "upsample2: C=%d must be a multiple of 8", C);
+  const long long total = (long long)d.N * d.vox() * (C / 8);
+  if (dtype == SEUNET_BF16)
+    upsample2_bwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)g_out, C, (bf16_t*)g_in, accumulate, d.D, d.H, d.W, total);
+  else
+    upsample2_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)g_out, C, (float*)g_in, accumulate, d.D, d.H, d.W, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_side_upsample(const float* side, int C, int scale, float* out, int c_total, int c_off, Dims dl,
+                         hipStream_t s) {
+  const long long total = (long long)dl.N * dl.vox() * scale * scale * scale;
+  side_upsample_kernel<<<grid_for(total), 256, 0, s>>>(side, C, scale, out, c_total, c_off, dl.D, dl.H, dl.W, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_head_fwd(const float* const* level_maps, int nlevels, const float* bias, float* pred, Dims d0,
+                    hipStream_t s) {
+  SEUNET_CHECK(nlevels >= 1 && nlevels <= 4, "head: nlevels=%d out of range", nlevels);
+  HeadLevels lv;
+  for (int l = 0; l < 4; ++l) lv.map[l] = l < nlevels ? level_maps[l] : nullptr;
+  for (int l = 1; l < nlevels; ++l)
+    SEUNET_CHECK((d0.D >> l) >= 1 && (d0.H >> l) >= 1 && (d0.W >> l) >= 1, "head: volume too small for level %d", l);
+  const long long total = (long long)d0.N * d0.vox();
+  head_fwd_kernel<<<grid_for(total), 256, 0, s>>>(lv, bias, pred, d0.D, d0.H, d0.W, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t head_bwd_tmp_floats(Dims d0) { return (size_t)d0.N * d0.vox() + 2 * 4096; }
+
+// g_levels[0] is not written (level 0 uses g_pred itself); g_levels[l>=1] receive the transposed
+// interpolation of g_pred; g_bias (optional) receives sum(g_pred).
+int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, float* tmp, float* g_bias,
+                    Dims d0, hipStream_t s) {
+  SEUNET_CHECK(nlevels >= 1 && nlevels <= 4, "head: nlevels=%d out of range", nlevels);
+  const long long V0 = d0.vox();
+  for (int l = 1; l < nlevels; ++l) {
+    if (!g_levels[l]) continue;
+    const int Dl = d0.D >> l, Hl = d0.H >> l, Wl = d0.W >> l;
+    float* t1 = tmp;                                        // [N][D0][H0][Wl]
+    float* t2 = tmp + (long long)d0.N * d0.D * d0.H * Wl;   // [N][D0][Hl][Wl]
+    long long tot = (long long)d0.N * d0.D * d0.H * Wl;
+    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(g_pred, t1, Wl, d0.W, 1, tot);
+    tot = (long long)d0.N * d0.D * Hl * Wl;
+    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(t1, t2, Hl, d0.H, Wl, tot);
+    tot = (long long)d0.N * Dl * Hl * Wl;
+    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(t2, g_levels[l], Dl, d0.D, (long long)Hl * Wl, tot);
+    SEUNET_LAUNCH_CHECK();
+  }
+  if (g_bias) {
+    double* part = reinterpret_cast<double*>(tmp + (((size_t)d0.N * V0 + 1) & ~(size_t)1));
+    sum_stage1_kernel<<<256, 256, 0, s>>>(g_pred, (long long)d0.N * V0, part);
+    sum_stage2_kernel<<<1, 64, 0, s>>>(part, 256, g_bias);
+    SEUNET_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace seunet

@@ -1,0 +1,220 @@
+// Shared declarations for the SE-UNet gfx950 library (internal; the public C ABI is
+// include/seunet_hip.h).  Activations are channels-last  [N][D][H][W][C]  with C a
+// multiple of 8, stored as f32 or bf16; all reductions and accumulators are f32/f64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define SEUNET_F32 0
+#define SEUNET_BF16 1
+
+typedef __bf16 bf16_t;
+
+namespace seunet {
+
+// ---- error plumbing (never throws across the ABI) -------------------------------
+void set_error(const std::string& msg);
+const char* get_error();
+int fail(const char* fmt, ...);
+
+#define SEUNET_CHECK(cond, ...)                       \
+  do {                                                \
+    if (!(cond)) return ::seunet::fail(__VA_ARGS__);  \
+  } while (0)
+
+#define SEUNET_HIP(expr)                                                              \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return ::seunet::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                            __FILE__, __LINE__);                                      \
+  } while (0)
+
+#define SEUNET_LAUNCH_CHECK()                                                          \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess)                                                             \
+      return ::seunet::fail("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                      \
+  } while (0)
+
+static inline size_t dtype_size(int dtype) { return dtype == SEUNET_BF16 ? 2 : 4; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- small POD descriptors shared by launchers and the net executor ---------------
+struct Dims {
+  int N, D, H, W;
+  long long vox() const { return (long long)D * H * W; }
+};
+
+struct SrcList {           // virtual channel concatenation of up to 3 tensors
+  const void* ptr[3];
+  int C[3];
+  int n;
+  int total() const { int t = 0; for (int i = 0; i < n; ++i) t += C[i]; return t; }
+};
+
+struct DstList {           // channel split of an output over up to 3 tensors
+  void* ptr[3];            // may be null: that channel range is computed but dropped
+  int C[3];
+  int acc[3];              // 1: read-modify-write (+=), 0: overwrite
+  int n;
+  int total() const { int t = 0; for (int i = 0; i < n; ++i) t += C[i]; return t; }
+};
+
+// ---- device helpers ----------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned int hi16) {
+  return __uint_as_float(hi16 << 16);
+}
+__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
+  bf16_t b = (bf16_t)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return (unsigned int)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 8 consecutive channels <-> 8 floats
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0];
+  const float4 b = reinterpret_cast<const float4*>(p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  v[0] = bf16_bits_to_f32(u.x & 0xffffu); v[1] = bf16_bits_to_f32(u.x >> 16);
+  v[2] = bf16_bits_to_f32(u.y & 0xffffu); v[3] = bf16_bits_to_f32(u.y >> 16);
+  v[4] = bf16_bits_to_f32(u.z & 0xffffu); v[5] = bf16_bits_to_f32(u.z >> 16);
+  v[6] = bf16_bits_to_f32(u.w & 0xffffu); v[7] = bf16_bits_to_f32(u.w >> 16);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+  u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+  u.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
+  u.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+// sum over the LPV (power of two, <= 64) consecutive lanes that share one voxel
+template <int LPV> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = 1; off < LPV; off <<= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// sum over all lanes with the same (lane % LPV): the lanes holding the same channels
+template <int LPV> __device__ __forceinline__ float stride_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= LPV; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+#endif  // __HIPCC__
+
+// ---- launcher prototypes (one per kernel family; defined in the .hip files) ----------
+// layout
+int launch_pack_input(int dtype, const float* x_ncdhw, int in_channel, void* out_cl8, Dims d, hipStream_t s);
+int launch_unpack_cl(int dtype, const void* in_cl, int C, float* out_ncdhw, Dims d, hipStream_t s);
+int launch_pack_cl(int dtype, const float* in_ncdhw, int C, void* out_cl, int Cpad, Dims d, hipStream_t s);
+
+// convolution (conv_igemm.hip)
+size_t conv_wpack_bytes(int dtype, int taps, int cin, int cout);
+int launch_conv_pack_weights(int dtype, const float* w_torch, int taps, int cin_w, int cout_w,
+                             int transpose_flip, void* wpack, hipStream_t s);
+int conv_stats_tiles(Dims d);     // partial-stat slots per sample written by the igemm kernel
+int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_logical,
+                      const void* wpack, const float* bias, const DstList& dst,
+                      float* stats_partial, Dims d, hipStream_t s);
+int launch_conv_naive(int dtype, int taps, int dil, const SrcList& src, int cin_logical,
+                      const float* w_torch, int transpose_flip, const float* bias,
+                      const DstList& dst, Dims d, hipStream_t s);
+
+// weight gradient (wgrad.hip)
+size_t wgrad_workspace_bytes(int taps, int cin, int cout);
+int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy,
+                 int cout, float* dw_torch, void* workspace, size_t ws_bytes, Dims d,
+                 hipStream_t s);
+int launch_wgrad_naive(int dtype, int taps, int dil, const SrcList& x, int cin_logical,
+                       const void* dy, int cout, float* dw_torch, Dims d, hipStream_t s);
+
+// normalisation / gates / cat (epilogue.hip)
+int epi_partials(Dims d);         // partial slots per sample used by the epilogue kernels
+int launch_channel_stats(int dtype, const void* t, int C, float* partial, Dims d, hipStream_t s);
+int launch_stats_finalize(const float* partial, int slots, int C, int N, long long count,
+                          float eps, int mode, float* out_a, float* out_b, hipStream_t s);
+struct SseParams {
+  const float* w_se;      // [C]
+  const float* w_se2;     // [C] or null (one gate)
+  const float* w_side;    // [2][C]
+  const float* b_side;    // [2]
+  float slope;
+};
+struct SseHead {          // how the 2-channel side output is consumed
+  float* side_out;        // fp32 [N][V][2] or null
+  float* level_map;       // fp32 [N][V] head pre-activation map of this level, or null
+  int level_accumulate;   // 0: overwrite level_map, 1: +=
+  const float* head_w;    // [2] head weights of this block's two channels
+  const float* drop;      // [N][drop_stride] DropLayer scales (points at this block's channel 0) or null
+  int drop_stride;
+};
+int launch_sse_fwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
+                   const SseParams& p, void* e_out, const SseHead& head, Dims d, hipStream_t s);
+struct SseBwdIn {
+  const void* g_e;        // gradient w.r.t. e (T) or null
+  const float* g_side;    // fp32 [N][V][2] gradient w.r.t. the side map, or null
+  const float* g_level;   // fp32 [N][V] gradient w.r.t. the level map, or null
+};
+// partial parameter-gradient record per (sample, slot):  4*C + 4 floats
+//   [0,C) dw_se  [C,2C) dw_se2  [2C,4C) dw_side[2][C]  [4C,4C+2) db_side  [4C+2,4C+4) dhead_w
+int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
+                   const SseParams& p, const SseBwdIn& g, const SseHead& head, void* dxhat_out,
+                   float* stat_partial, float* pgrad_partial, Dims d, hipStream_t s);
+int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* dw_se,
+                        float* dw_se2, float* dw_side, float* db_side, float* dhead_w,
+                        hipStream_t s);
+int launch_in_bwd_apply(int dtype, void* dxhat_inout, const void* raw, const float* mean,
+                        const float* rstd, const float* m1, const float* m2, int C, Dims d,
+                        hipStream_t s);
+int launch_cat_fwd(int dtype, const void* raw, const float* mean, const float* rstd,
+                   const void* raw2, const float* mean2, const float* rstd2, int C, float slope,
+                   void* out, Dims d, hipStream_t s);
+int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* mean,
+                   const float* rstd, const void* raw2, const float* mean2, const float* rstd2,
+                   int C, float slope, void* dxhat_out, void* dxhat2_out, float* stat_partial,
+                   float* stat_partial2, Dims d, hipStream_t s);
+
+// pooling / interpolation / heads (resample.hip)
+int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);
+int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void* g_in,
+                       int accumulate, Dims din, hipStream_t s);
+int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);
+int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate,
+                         Dims din, hipStream_t s);
+int launch_side_upsample(const float* side, int C, int scale, float* out_ncdhw, int c_total,
+                         int c_off, Dims dlow, hipStream_t s);
+int launch_head_fwd(const float* const* level_maps, int nlevels, const float* bias, float* pred,
+                    Dims d0, hipStream_t s);
+int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, float* tmp,
+                    float* g_bias, Dims d0, hipStream_t s);
+size_t head_bwd_tmp_floats(Dims d0);
+
+// losses (loss.hip)
+#define SEUNET_LOSS_NSUMS 7
+int loss_partials();
+int launch_loss_sums(const float* pred, int apply_sigmoid, const float* target,
+                     const float* weight, const float* skel, long long n, float* partial,
+                     double* sums, hipStream_t s);
+int launch_loss_grad(const float* pred, int apply_sigmoid, const float* target,
+                     const float* weight, const float* skel, long long n, const double* sums,
+                     float c_dice, float c_gul, float c_atr, float g_scale,
+                     const float* g_scale_dev, float* g_pred, hipStream_t s);
+}  // namespace seunet

@@ -1,0 +1,309 @@
+// Weight gradient of the 3x3x3 / 1x1x1 convolutions on gfx950 matrix cores.
+//   dW[co][ci][tap] = sum over (n, voxel v) of  X[n][v + off(tap)][ci] * dY[n][v][co]
+// (backward of nn.Conv3d at reference SE_UNet.py:15,42,57; X may be a fused channel concatenation.)
+//
+//   GEMM view   M = input channels (32 per workgroup), N = output channels (32), K = voxels
+//   workgroup   256 threads = 4 waves, persistent over spatial tiles; LDS holds the X halo tile and the
+//               dY tile as [voxel][32 channels]; the 27 taps are split over the 4 waves (7/7/7/6), each wave
+//               keeping one 32x32 f32 accumulator per tap in registers across ALL its tiles
+//   MFMA        v_mfma_f32_32x32x2_f32 (K-step = 2 voxels; operands are one element per lane, so the
+//               [voxel][channel] LDS image is read with plain conflict-free loads, bf16 widened on read)
+//   output      each workgroup stores its accumulators once to a slab; a second kernel sums the slabs in a
+//               fixed order (deterministic, no atomics) straight into the PyTorch (Cout,Cin,3,3,3) layout
+#include "seunet_common.h"
+
+namespace seunet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgArgs {
+  const void* src0; const void* src1; const void* src2;
+  int srcC0, srcC1, srcC2;
+  int cum1, cum2;
+  int cin;                 // logical input channels
+  const void* dy; int cout;
+  float* slab;
+  int N, D, H, W;
+  int tx, ty, tz;          // tile counts per sample
+  int co_tiles;
+};
+
+template <typename T, int DIL, int TAPS> struct WgTile;
+template <int TAPS> struct WgTile<bf16_t, 1, TAPS> { static constexpr int TZ = 4, TY = 4; };
+template <int TAPS> struct WgTile<bf16_t, 2, TAPS> { static constexpr int TZ = 2, TY = 4; };
+template <int TAPS> struct WgTile<float, 1, TAPS> { static constexpr int TZ = 2, TY = 4; };
+template <int TAPS> struct WgTile<float, 2, TAPS> { static constexpr int TZ = 1, TY = 2; };
+
+template <typename T, int TAPS, int DIL>
+__global__ void __launch_bounds__(256)
+wgrad_kernel(WgArgs a) {
+  constexpr int HALO = (TAPS == 27) ? DIL : 0;
+  constexpr int TZ = WgTile<T, DIL, TAPS>::TZ, TY = WgTile<T, DIL, TAPS>::TY, TX = 32;
+  constexpr int HZ = TZ + 2 * HALO, HY = TY + 2 * HALO, HX = TX + 2 * HALO;
+  constexpr int NVH = HZ * HY * HX, NVT = TZ * TY * TX;
+  constexpr int EPP = 16 / sizeof(T);   // elements per 16-byte piece
+  constexpr int PPV = 32 / EPP;         // pieces per voxel (32 channels)
+  constexpr int NT = (TAPS == 27) ? 7 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* xs = reinterpret_cast<T*>(smem);                       // [NVH][32]
+  T* ys = reinterpret_cast<T*>(smem) + (size_t)NVH * 32;    // [NVT][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int combo = blockIdx.y;
+  const int ci0 = (combo / a.co_tiles) * 32, co0 = (combo % a.co_tiles) * 32;
+  const long long V = (long long)a.D * a.H * a.W;
+  const int tiles_per_sample = a.tx * a.ty * a.tz;
+  const int total_tiles = tiles_per_sample * a.N;
+
+  int tapoff[NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    int tap = wave + 4 * ti;
+    if (tap > TAPS - 1) tap = TAPS - 1;
+    if (TAPS == 27) tapoff[ti] = (((tap / 9) * HALO) * HY + ((tap / 3) % 3) * HALO) * HX + (tap % 3) * HALO;
+    else tapoff[ti] = 0;
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int n = tile / tiles_per_sample;
+    int t = tile % tiles_per_sample;
+    const int bx = t % a.tx; t /= a.tx;
+    const int by = t % a.ty;
+    const int bz = t / a.ty;
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    __syncthreads();
+    for (int idx = tid; idx < NVH * PPV; idx += 256) {
+      const int vox = idx / PPV, piece = idx % PPV;
+      const int hx = vox % HX;
+      const int r2 = vox / HX;
+      const int hy = r2 % HY, hz = r2 / HY;
+      const int gz = z0 - HALO + hz, gy = y0 - HALO + hy, gx = x0 - HALO + hx;
+      const int ch0 = ci0 + piece * EPP;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+          ch0 < a.cin) {
+        const void* sp = a.src0; int sC = a.srcC0, c = ch0;
+        if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
+        else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
+        val = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(sp) +
+              ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * sC + c);
+      }
+      *reinterpret_cast<uint4*>(xs + (size_t)vox * 32 + piece * EPP) = val;
+    }
+    for (int idx = tid; idx < NVT * PPV; idx += 256) {
+      const int vox = idx / PPV, piece = idx % PPV;
+      const int lx = vox % TX;
+      const int r2 = vox / TX;
+      const int ly = r2 % TY, lz = r2 / TY;
+      const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+      const int ch0 = co0 + piece * EPP;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if (gz < a.D && gy < a.H && gx < a.W && ch0 < a.cout)
+        val = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.dy) +
+              ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * a.cout + ch0);
+      *reinterpret_cast<uint4*>(ys + (size_t)vox * 32 + piece * EPP) = val;
+    }
+    __syncthreads();
+    for (int row = 0; row < TZ * TY; ++row) {
+      if (TAPS == 1 && (row & 3) != wave) continue;   // 1x1x1: rows are split over the waves
+      const int lz = row / TY, ly = row % TY;
+      const int xrow = ((lz * HY + ly) * HX) * 32;      // tap (0,0,0) row start in the halo tile
+      const int yrow = (row * TX) * 32;
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        const int xo = 2 * kk + h;
+        const float bfr = to_f32(ys[yrow + xo * 32 + col]);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+          const float afr = to_f32(xs[xrow + (tapoff[ti] + xo) * 32 + col]);
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr, bfr, acc[ti], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- store this workgroup's accumulators: slab[(combo*G + wg) (x4 waves for 1x1)][tap][ci][co] ----
+  if (TAPS == 27) {
+    float* out = a.slab + ((size_t)combo * gridDim.x + blockIdx.x) * (27 * 1024);
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      const int tap = wave + 4 * ti;
+      if (tap < 27) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          out[(tap * 32 + row) * 32 + col] = acc[ti][r];
+        }
+      }
+    }
+  } else {
+    float* out = a.slab + (((size_t)combo * gridDim.x + blockIdx.x) * 4 + wave) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[row * 32 + col] = acc[0][r];
+    }
+  }
+}
+
+// dW (PyTorch layout) = fixed-order sum of the slabs
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int taps, int cin_w, int cout_w,
+                                    int co_tiles, float* __restrict__ dw, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const int ci = (int)((i / taps) % cin_w);
+    const int co = (int)(i / ((long long)taps * cin_w));
+    const int combo = (ci / 32) * co_tiles + co / 32;
+    const float* p = slab + (size_t)combo * nslab * (taps * 1024) + ((size_t)tap * 32 + (ci & 31)) * 32 + (co & 31);
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += (double)p[(size_t)k * (taps * 1024)];
+    dw[i] = (float)s;
+  }
+}
+
+static inline int wgrad_groups(int taps, int combos, int total_tiles) {
+  int g = 1024 / combos;
+  if (g < 32) g = 32;
+  if (g > 512) g = 512;
+  if (g > total_tiles) g = total_tiles;
+  if (g < 1) g = 1;
+  (void)taps;
+  return g;
+}
+
+size_t wgrad_workspace_bytes(int taps, int cin, int cout) {
+  const int combos = cdiv(cin, 32) * cdiv(cout, 32);
+  const int g = 1024 / combos < 32 ? 32 : (1024 / combos > 512 ? 512 : 1024 / combos);
+  return (size_t)combos * g * (taps == 27 ? 27 : 4) * 1024 * sizeof(float);
+}
+
+template <typename T, int TAPS, int DIL>
+static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int HALO = (TAPS == 27) ? DIL : 0;
+  constexpr int TZ = WgTile<T, DIL, TAPS>::TZ, TY = WgTile<T, DIL, TAPS>::TY;
+  constexpr int LDS = ((TZ + 2 * HALO) * (TY + 2 * HALO) * (32 + 2 * HALO) + TZ * TY * 32) * 32 * (int)sizeof(T);
+  static bool configured = false;
+  if (!configured) {
+    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    configured = true;
+  }
+  wgrad_kernel<T, TAPS, DIL><<<grid, 256, LDS, s>>>(a);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static void wgrad_tile_dims(int taps, int dil, int& tz, int& ty) {
+  if (taps == 1 || dil == 1) { tz = WgTile<T, 1, 27>::TZ; ty = WgTile<T, 1, 27>::TY; }
+  else { tz = WgTile<T, 2, 27>::TZ; ty = WgTile<T, 2, 27>::TY; }
+}
+
+// x: input activation (may be a concatenation), cin_logical leading channels carry weights;
+// dy: gradient w.r.t. the raw conv output, [N][V][cout]; dw: (cout, cin_logical, taps) f32, overwritten.
+int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy, int cout,
+                 float* dw, void* workspace, size_t ws_bytes, Dims d, hipStream_t s) {
+  SEUNET_CHECK(taps == 27 || taps == 1, "wgrad: taps=%d unsupported", taps);
+  SEUNET_CHECK(taps == 1 || dil == 1 || dil == 2, "wgrad: dilation %d unsupported", dil);
+  SEUNET_CHECK(x.n >= 1 && x.n <= 3, "wgrad: 1..3 sources");
+  SEUNET_CHECK(cout % 8 == 0 && cin_logical >= 1 && cin_logical <= x.total(), "wgrad: bad channel counts");
+  SEUNET_CHECK(ws_bytes >= wgrad_workspace_bytes(taps, cin_logical, cout), "wgrad: workspace too small");
+  WgArgs a{};
+  a.src0 = x.ptr[0]; a.srcC0 = x.C[0];
+  a.src1 = x.n > 1 ? x.ptr[1] : nullptr; a.srcC1 = x.n > 1 ? x.C[1] : 0;
+  a.src2 = x.n > 2 ? x.ptr[2] : nullptr; a.srcC2 = x.n > 2 ? x.C[2] : 0;
+  a.cin = cin_logical;
+  a.cum1 = x.n > 1 ? x.C[0] : x.total();
+  a.cum2 = x.n > 2 ? x.C[0] + x.C[1] : x.total();
+  a.dy = dy; a.cout = cout;
+  a.slab = reinterpret_cast<float*>(workspace);
+  a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
+  int tz, ty;
+  if (dtype == SEUNET_BF16) wgrad_tile_dims<bf16_t>(taps, dil, tz, ty); else wgrad_tile_dims<float>(taps, dil, tz, ty);
+  a.tx = cdiv(d.W, 32); a.ty = cdiv(d.H, ty); a.tz = cdiv(d.D, tz);
+  a.co_tiles = cdiv(cout, 32);
+  const int combos = cdiv(cin_logical, 32) * a.co_tiles;
+  const int G = wgrad_groups(taps, combos, a.tx * a.ty * a.tz * d.N);
+  dim3 grid(G, combos);
+  int e;
+  if (dtype == SEUNET_BF16) {
+    if (taps == 1) e = wgrad_launch_one<bf16_t, 1, 1>(a, grid, s);
+    else if (dil == 1) e = wgrad_launch_one<bf16_t, 27, 1>(a, grid, s);
+    else e = wgrad_launch_one<bf16_t, 27, 2>(a, grid, s);
+  } else {
+    if (taps == 1) e = wgrad_launch_one<float, 1, 1>(a, grid, s);
+    else if (dil == 1) e = wgrad_launch_one<float, 27, 1>(a, grid, s);
+    else e = wgrad_launch_one<float, 27, 2>(a, grid, s);
+  }
+  if (e) return e;
+  const long long total = (long long)cout * cin_logical * taps;
+  const int nslab = taps == 27 ? G : 4 * G;
+  wgrad_reduce_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
+      a.slab, nslab, taps, cin_logical, cout, a.co_tiles, dw, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// naive weight gradient: one thread per weight element (device-side cross-check, small sizes only)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void wgrad_naive_kernel(WgArgs a, int taps, int dil, float* __restrict__ dw, long long total) {
+  const long long V = (long long)a.D * a.H * a.W;
+  const int t3 = taps == 27 ? 3 : 1, c = taps == 27 ? 1 : 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const int ci = (int)((i / taps) % a.cin);
+    const int co = (int)(i / ((long long)taps * a.cin));
+    const int dz = (tap / (t3 * t3) - c) * dil, dy = ((tap / t3) % t3 - c) * dil, dx = (tap % t3 - c) * dil;
+    const void* sp = a.src0; int sC = a.srcC0, cc = ci;
+    if (ci >= a.cum2) { sp = a.src2; sC = a.srcC2; cc = ci - a.cum2; }
+    else if (ci >= a.cum1) { sp = a.src1; sC = a.srcC1; cc = ci - a.cum1; }
+    double s = 0.0;
+    for (int n = 0; n < a.N; ++n)
+      for (int z = 0; z < a.D; ++z) {
+        const int zz = z + dz;
+        if ((unsigned)zz >= (unsigned)a.D) continue;
+        for (int y = 0; y < a.H; ++y) {
+          const int yy = y + dy;
+          if ((unsigned)yy >= (unsigned)a.H) continue;
+          for (int x = 0; x < a.W; ++x) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)a.W) continue;
+            const float xv = to_f32(reinterpret_cast<const T*>(sp)[(n * V + ((long long)zz * a.H + yy) * a.W + xx) * sC + cc]);
+            const float gv = to_f32(reinterpret_cast<const T*>(a.dy)[(n * V + ((long long)z * a.H + y) * a.W + x) * a.cout + co]);
+            s += (double)xv * (double)gv;
+          }
+        }
+      }
+    dw[i] = (float)s;
+  }
+}
+
+int launch_wgrad_naive(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy, int cout,
+                       float* dw, Dims d, hipStream_t s) {
+  WgArgs a{};
+  a.src0 = x.ptr[0]; a.srcC0 = x.C[0];
+  a.src1 = x.n > 1 ? x.ptr[1] : nullptr; a.srcC1 = x.n > 1 ? x.C[1] : 0;
+  a.src2 = x.n > 2 ? x.ptr[2] : nullptr; a.srcC2 = x.n > 2 ? x.C[2] : 0;
+  a.cin = cin_logical;
+  a.cum1 = x.n > 1 ? x.C[0] : x.total();
+  a.cum2 = x.n > 2 ? x.C[0] + x.C[1] : x.total();
+  a.dy = dy; a.cout = cout;
+  a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
+  const long long total = (long long)cout * cin_logical * taps;
+  const int grid = (int)((total + 63) / 64);
+  if (dtype == SEUNET_BF16) wgrad_naive_kernel<bf16_t><<<grid, 64, 0, s>>>(a, taps, dil, dw, total);
+  else wgrad_naive_kernel<float><<<grid, 64, 0, s>>>(a, taps, dil, dw, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace seunet

@@ -1,0 +1,107 @@
+"""Losses of the reference training loops (train.py:51-76) on HIP reduction kernels.
+
+``dice_loss`` / ``general_union_loss_lib`` / ``atr_loss`` keep the reference signatures: they take
+*probabilities* (the reference applies ``torch.sigmoid`` first, train.py:595-596) of any
+broadcast-compatible shape and return a scalar tensor that supports ``.backward()``.
+``fused_stage_loss`` is the same arithmetic taken from raw logits in one pass per head (sigmoid and
+its derivative folded into the kernels).
+
+All three are ratios of WHOLE-BATCH sums.  Under one-process-per-GPU data parallelism
+pass ``group=`` (a torch.distributed process group): the 7 partial sums are all-reduced before the
+ratio is formed, which reproduces the reference's single-process global-batch objective exactly
+(then SUM, not average, the parameter gradients across ranks).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _prep(t: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return torch.broadcast_to(t.to(like.device, torch.float32), like.shape).contiguous()
+
+
+def _sums(pred, apply_sigmoid, target, weight, skel, group):
+    lib = _lib.load()
+    n = pred.numel()
+    partial = torch.empty(lib.seunet_loss_partial_floats(), dtype=torch.float32, device=pred.device)
+    sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=pred.device)
+    _lib.check(lib.seunet_loss_sums(pred.data_ptr(), int(apply_sigmoid), target.data_ptr(), _lib.ptr(weight), _lib.ptr(skel),
+                                    n, partial.data_ptr(), sums.data_ptr(), _lib.stream_ptr()), "loss_sums")
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group if group is not True else None)
+    return sums
+
+
+def _value(sums, c_dice, c_gul, c_atr):
+    out = sums.new_zeros(())
+    if c_dice:
+        out = out + c_dice * (1 - (2 * sums[0] + 1) / (sums[1] + sums[2] + 1))
+    if c_gul:
+        out = out + c_gul * (1 - (sums[3] + 1) / (sums[4] + 1))
+    if c_atr:
+        out = out + c_atr * (1 - (sums[5] + 1) / (sums[6] + 1))
+    return out.to(torch.float32)
+
+
+class _RatioLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight, skel, c_dice, c_gul, c_atr, apply_sigmoid, group):
+        if not pred.is_cuda:
+            raise RuntimeError("HIP losses need GPU tensors (no CPU fallback; the CPU oracle is oracle/seunet_oracle.py)")
+        p = pred.detach().contiguous().float()
+        t, w, s = _prep(target, p), _prep(weight, p), _prep(skel, p)
+        sums = _sums(p, apply_sigmoid, t, w, s, group)
+        ctx.saved = (p, t, w, s, sums)
+        ctx.coef = (float(c_dice), float(c_gul), float(c_atr), bool(apply_sigmoid))
+        ctx.shape = pred.shape
+        return _value(sums, c_dice, c_gul, c_atr)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, w, s, sums = ctx.saved
+        c_dice, c_gul, c_atr, sig = ctx.coef
+        gp = torch.empty_like(p)
+        gs = g.detach().reshape(1).to(torch.float32).contiguous()
+        _lib.check(_lib.load().seunet_loss_grad(p.data_ptr(), int(sig), t.data_ptr(), _lib.ptr(w), _lib.ptr(s), p.numel(),
+                                                sums.data_ptr(), c_dice, c_gul, c_atr, 1.0, gs.data_ptr(), gp.data_ptr(),
+                                                _lib.stream_ptr()), "loss_grad")
+        return gp.reshape(ctx.shape), None, None, None, None, None, None, None, None
+
+
+def dice_loss(pred, target, group=None):
+    """train.py:51-57."""
+    return _RatioLoss.apply(pred, target, None, None, 1.0, 0.0, 0.0, False, group)
+
+
+def general_union_loss_lib(pred, target, weight, group=None):
+    """train.py:59-68 (alpha 0.2, exponent 0.7)."""
+    return _RatioLoss.apply(pred, target, weight, None, 0.0, 1.0, 0.0, False, group)
+
+
+def atr_loss(pred, target, skel, weight, group=None):
+    """train.py:70-76 (``target`` is ignored by the reference and here)."""
+    return _RatioLoss.apply(pred, target, weight, skel, 0.0, 0.0, 1.0, False, group)
+
+
+def fused_logit_loss(logits, target, weight=None, skel=None, c_dice=1.0, c_gul=0.0, c_atr=0.0, group=None):
+    """c_dice*dice + c_gul*GUL + c_atr*ATR of sigmoid(logits), one reduction pass + one gradient pass."""
+    return _RatioLoss.apply(logits, target, weight, skel, c_dice, c_gul, c_atr, True, group)
+
+
+def fused_stage_loss(stage: int, pred_en, pred_de, label, weight=None, skel=None, group=None):
+    """Loss of training stage 1/2/3 from the raw logits of both heads
+    (train.py:595-599 ; 429-435 ; 235-243)."""
+    if stage == 1:
+        return fused_logit_loss(pred_de, label, group=group) + fused_logit_loss(pred_en, label, group=group)
+    if stage == 2:
+        return (fused_logit_loss(pred_de, label, weight, None, 0.0, 1.0, 0.0, group)
+                + fused_logit_loss(pred_en, label, weight, None, 0.0, 0.5, 0.0, group))
+    return (fused_logit_loss(pred_de, label, weight, skel, 0.0, 1.0, 0.5, group)
+            + fused_logit_loss(pred_en, label, weight, skel, 0.0, 0.5, 0.5, group))

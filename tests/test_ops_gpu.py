@@ -1,0 +1,335 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the same op on the CPU in fp32 torch.
+
+f32 kernels must agree to ~1e-5 relative; bf16 kernels are compared against the fp32 op applied to
+bf16-rounded inputs (so what is measured is the kernel, not input quantisation) with a tolerance of a few
+bf16 ulps of the output range.  Shapes are deliberately not multiples of the tile sizes (masking)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import seunet_amd
+    from seunet_amd import _lib, ops
+    _lib.load()
+    return ops
+
+
+DT = ["fp32", "bf16"]
+IMPL = [0, 1]  # MFMA, naive
+
+
+def rnd(dtype, t):
+    return t.to(torch.bfloat16).float() if dtype == "bf16" else t
+
+
+def tol(dtype, ref):
+    scale = float(ref.abs().max()) + 1e-12
+    return (2e-5 if dtype == "fp32" else 1.2e-2) * scale
+
+
+def assert_close(got, ref, dtype, what=""):
+    got, ref = got.detach().cpu().float(), ref.detach().cpu().float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = float((got - ref).abs().max())
+    assert err <= tol(dtype, ref), f"{what}: max|err|={err:.3e} tol={tol(dtype, ref):.3e} ref max={float(ref.abs().max()):.3e}"
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layout_roundtrip(S, dtype):
+    x = gen(2, 5, 4, 6, 10, seed=1)
+    cl = S.to_cl(x.cuda(), dtype)
+    assert cl.shape == (2, 4, 6, 10, 8)
+    back = S.from_cl(cl, 5).cpu()
+    assert_close(back, rnd(dtype, x), dtype, "roundtrip")
+    assert float(S.from_cl(cl).cpu()[:, 5:].abs().max()) == 0.0
+
+
+CONV_CASES = [
+    # (src channel split, logical cin, cout, dilation)
+    ([8], 2, 8, 1),            # ec1: padded network input
+    ([8], 8, 16, 1),           # ec2
+    ([16], 16, 32, 2),         # ec3
+    ([32, 32], 64, 32, 1),     # dc5 (fused cat)
+    ([64], 64, 64, 2),         # ec8/ec9
+    ([64, 64], 128, 64, 1),    # dc1/dc3
+    ([32], 32, 16, 1),         # dc6
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("impl", IMPL)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3x3_forward_and_stats(S, dtype, impl, case):
+    split, cin, cout, dil = case
+    n, d, h, w = 2, 6, 9, 40
+    x = rnd(dtype, gen(n, sum(split), d, h, w, seed=2))
+    if cin < sum(split):
+        x[:, cin:] = 0
+    wt = rnd(dtype, gen(cout, cin, 3, 3, 3, seed=3, scale=(27 * cin) ** -0.5))
+    b = gen(cout, seed=4, scale=0.1)
+    ref = F.conv3d(x[:, :cin], wt, b, padding=dil, dilation=dil)
+    srcs, o = [], 0
+    for c in split:
+        srcs.append(S.to_cl(x[:, o:o + c].cuda(), dtype))
+        o += c
+    (raw,), part, slots = S.conv3d(srcs, wt.cuda(), b.cuda(), dil, impl, cin=cin, want_stats=True)
+    got = S.from_cl(raw, cout)
+    assert_close(got, ref, dtype, "conv")
+    mean, rstd = S.stats_finalize(part, slots, d * h * w)
+    src_stats = ref if impl == 0 else got.cpu()   # MFMA path takes stats from the f32 accumulators
+    rm = src_stats.mean(dim=(2, 3, 4))
+    rv = src_stats.var(dim=(2, 3, 4), unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), rm.numpy(), atol=3e-3 if dtype == "bf16" else 2e-5)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (rv + 1e-5).rsqrt().numpy(), rtol=2e-2 if dtype == "bf16" else 2e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("impl", IMPL)
+@pytest.mark.parametrize("split,cout", [([32, 8, 16], 32), ([64, 64, 64], 64), ([32, 64], 32), ([8], 32)])
+def test_conv1x1x1_forward(S, dtype, impl, split, cout):
+    n, d, h, w = 2, 5, 7, 33
+    cin = sum(split) if split != [8] else 2
+    x = rnd(dtype, gen(n, sum(split), d, h, w, seed=5))
+    if cin < sum(split):
+        x[:, cin:] = 0
+    wt = rnd(dtype, gen(cout, cin, 1, 1, 1, seed=6, scale=cin ** -0.5))
+    ref = F.conv3d(x[:, :cin], wt)
+    srcs, o = [], 0
+    for c in split:
+        srcs.append(S.to_cl(x[:, o:o + c].cuda(), dtype))
+        o += c
+    (raw,), _, _ = S.conv3d(srcs, wt.cuda(), None, 1, impl, cin=cin)
+    assert_close(S.from_cl(raw, cout), ref, dtype, "conv1x1")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("impl", IMPL)
+@pytest.mark.parametrize("case", [([32, 32], 32, 1, 27), ([16], 32, 2, 27), ([64, 64], 64, 1, 27),
+                                  ([32, 8, 16], 32, 1, 1), ([32, 64], 32, 1, 1)])
+def test_conv_data_gradient(S, dtype, impl, case):
+    """dgrad = same kernel on flipped/transposed weights, split over the concatenated inputs, with +=."""
+    split, cout, dil, taps = case
+    k = 3 if taps == 27 else 1
+    n, d, h, w = 2, 6, 6, 36
+    cin = sum(split)
+    wt = rnd(dtype, gen(cout, cin, k, k, k, seed=7, scale=(taps * cin) ** -0.5))
+    dy = rnd(dtype, gen(n, cout, d, h, w, seed=8))
+    x = torch.zeros(n, cin, d, h, w, requires_grad=True)
+    F.conv3d(x, wt, padding=dil if k == 3 else 0, dilation=dil if k == 3 else 1).backward(dy)
+    ref = x.grad
+    prev = rnd(dtype, gen(n, split[0], d, h, w, seed=9))          # first destination accumulates
+    dsts = [S.to_cl(prev.cuda(), dtype)] + [torch.empty((n, d, h, w, c), dtype=S._tdtype(S._lib.dtype_code(dtype)), device="cuda")
+                                            for c in split[1:]]
+    S.conv3d([S.to_cl(dy.cuda(), dtype)], wt.cuda(), None, dil, impl, transpose_flip=True, dsts=dsts,
+             accumulate=[1] + [0] * (len(split) - 1))
+    o = 0
+    for i, c in enumerate(split):
+        want = ref[:, o:o + c] + (prev if i == 0 else 0)
+        assert_close(S.from_cl(dsts[i]), rnd(dtype, want) if dtype == "bf16" else want, dtype, f"dgrad dst{i}")
+        o += c
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("impl", IMPL)
+@pytest.mark.parametrize("case", [([8], 2, 8, 1, 27), ([16], 16, 32, 2, 27), ([32, 32], 64, 32, 1, 27),
+                                  ([64], 64, 64, 2, 27), ([32, 8, 16], 56, 32, 1, 1), ([8], 2, 32, 1, 1)])
+def test_conv_weight_gradient(S, dtype, impl, case):
+    split, cin, cout, dil, taps = case
+    k = 3 if taps == 27 else 1
+    n, d, h, w = 2, 5, 6, 40
+    x = rnd(dtype, gen(n, sum(split), d, h, w, seed=10))
+    dy = rnd(dtype, gen(n, cout, d, h, w, seed=11))
+    wt = torch.zeros(cout, cin, k, k, k, requires_grad=True)
+    F.conv3d(x[:, :cin], wt, padding=dil if k == 3 else 0, dilation=dil if k == 3 else 1).backward(dy)
+    srcs, o = [], 0
+    for c in split:
+        srcs.append(S.to_cl(x[:, o:o + c].cuda(), dtype))
+        o += c
+    dw = S.conv3d_wgrad(srcs, S.to_cl(dy.cuda(), dtype), cin, cout, taps, dil, impl)
+    assert_close(dw, wt.grad, "fp32", "wgrad")   # accumulation is f32 in both modes
+
+
+def _block_ref(raw, w_se, w_se2, w_side, b_side, slope=0.01):
+    e = F.leaky_relu(F.instance_norm(raw), slope)
+    e = e * torch.sigmoid(F.conv3d(e, w_se))
+    if w_se2 is not None:
+        e = e * torch.sigmoid(F.conv3d(e, w_se2))
+    return e, F.conv3d(e, w_side, b_side)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,gates", [(8, 1), (16, 1), (32, 2), (64, 2)])
+def test_gate_epilogue_forward_backward(S, dtype, c, gates):
+    n, d, h, w = 2, 6, 10, 12
+    raw = rnd(dtype, gen(n, c, d, h, w, seed=12) * 2 + 0.3).requires_grad_(True)
+    w_se, w_se2 = gen(1, c, 1, 1, 1, seed=13, scale=0.5), (gen(1, c, 1, 1, 1, seed=14, scale=0.5) if gates == 2 else None)
+    w_side, b_side = gen(2, c, 1, 1, 1, seed=15, scale=0.5), gen(2, seed=16, scale=0.1)
+    prm = [t.requires_grad_(True) for t in (w_se, w_se2, w_side, b_side) if t is not None]
+    e_ref, s_ref = _block_ref(raw, w_se, w_se2, w_side, b_side)
+    g_e = rnd(dtype, gen(n, c, d, h, w, seed=17))
+    g_s = gen(n, 2, d, h, w, seed=18)
+    (e_ref * g_e).sum().add((s_ref * g_s).sum()).backward()
+
+    raw_cl = S.to_cl(raw.detach().cuda(), dtype)
+    part, slots = S.channel_stats(raw_cl)
+    mean, rstd = S.stats_finalize(part, slots, d * h * w)
+    cu = lambda t: None if t is None else t.detach().cuda()
+    e, side = S.gate_epilogue_fwd(raw_cl, mean, rstd, cu(w_se), cu(w_se2), cu(w_side), cu(b_side))
+    assert_close(S.from_cl(e), e_ref, dtype, "e")
+    assert_close(side.permute(0, 4, 1, 2, 3), s_ref, "fp32" if dtype == "fp32" else "bf16", "side")
+    out = S.gate_epilogue_bwd(raw_cl, mean, rstd, cu(w_se), cu(w_se2), cu(w_side), cu(b_side), g_e=S.to_cl(g_e.cuda(), dtype),
+                              g_side=g_s.permute(0, 2, 3, 4, 1).contiguous().cuda())
+    assert_close(S.from_cl(out["draw"]), raw.grad, dtype, "draw")
+    looser = "fp32" if dtype == "fp32" else "bf16"
+    assert_close(out["dw_se"], w_se.grad.reshape(-1), looser, "dw_se")
+    if gates == 2:
+        assert_close(out["dw_se2"], w_se2.grad.reshape(-1), looser, "dw_se2")
+    assert_close(out["dw_side"], w_side.grad.reshape(-1), looser, "dw_side")
+    assert_close(out["db_side"], b_side.grad, looser, "db_side")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gate_epilogue_level_map_and_head_grad(S, dtype):
+    """The head weight / DropLayer scale applied at native resolution (SE_UNet.py:232-233 is linear)."""
+    n, c, d, h, w = 2, 16, 4, 6, 8
+    raw = rnd(dtype, gen(n, c, d, h, w, seed=19))
+    w_se, w_side, b_side = gen(1, c, 1, 1, 1, seed=20), gen(2, c, 1, 1, 1, seed=21), gen(2, seed=22)
+    head_w = gen(2, seed=23).requires_grad_(True)
+    drop = torch.tensor([[0.0, 1.3, 9, 9], [0.7, 0.7, 9, 9]])
+    _, s_ref = _block_ref(raw, w_se, None, w_side, b_side)
+    lvl_ref = (s_ref * (head_w.view(1, 2, 1, 1, 1) * drop[:, :2].view(n, 2, 1, 1, 1))).sum(1)
+    g_lvl = gen(n, d, h, w, seed=24)
+    (lvl_ref * g_lvl).sum().backward()
+    raw_cl = S.to_cl(raw.cuda(), dtype)
+    part, slots = S.channel_stats(raw_cl)
+    mean, rstd = S.stats_finalize(part, slots, d * h * w)
+    lvl = torch.full((n, d, h, w), 5.0, device="cuda")
+    S.gate_epilogue_fwd(raw_cl, mean, rstd, w_se.cuda(), None, w_side.cuda(), b_side.cuda(), level_map=lvl, level_accumulate=1,
+                        head_w=head_w.detach().cuda(), drop=drop.cuda(), drop_stride=4, want_side=False)
+    assert_close(lvl - 5.0, lvl_ref, dtype, "level map")
+    out = S.gate_epilogue_bwd(raw_cl, mean, rstd, w_se.cuda(), None, w_side.cuda(), b_side.cuda(), g_level=g_lvl.cuda(),
+                              head_w=head_w.detach().cuda(), drop=drop.cuda(), drop_stride=4)
+    assert_close(out["dhead_w"], head_w.grad, "fp32" if dtype == "fp32" else "bf16", "dhead_w")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("two", [False, True])
+def test_cat_epilogue_forward_backward(S, dtype, two):
+    n, c, d, h, w = 2, 32, 5, 6, 12
+    raw = rnd(dtype, gen(n, c, d, h, w, seed=25) + 0.2).requires_grad_(True)
+    raw2 = rnd(dtype, gen(n, c, d, h, w, seed=26) * 3).requires_grad_(True) if two else None
+    ref = F.leaky_relu(F.instance_norm(raw), 0.01)
+    if two:
+        ref = ref + F.leaky_relu(F.instance_norm(raw2), 0.01)
+    g = rnd(dtype, gen(n, c, d, h, w, seed=27))
+    (ref * g).sum().backward()
+
+    def stats(t):
+        cl = S.to_cl(t.detach().cuda(), dtype)
+        p, s = S.channel_stats(cl)
+        return (cl,) + S.stats_finalize(p, s, d * h * w)
+    a = stats(raw)
+    b = stats(raw2) if two else (None, None, None)
+    out = S.cat_epilogue_fwd(*a, *b)
+    assert_close(S.from_cl(out), ref, dtype, "cat out")
+    dx, dx2 = S.cat_epilogue_bwd(S.to_cl(g.cuda(), dtype), *a, *b)
+    assert_close(S.from_cl(dx), raw.grad, dtype, "cat draw")
+    if two:
+        assert_close(S.from_cl(dx2), raw2.grad, dtype, "cat draw2")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_maxpool_and_upsample(S, dtype):
+    n, c, d, h, w = 2, 16, 4, 6, 10
+    x = rnd(dtype, gen(n, c, d, h, w, seed=28)).requires_grad_(True)
+    p_ref = F.max_pool3d(x, 2, 2)
+    g = rnd(dtype, gen(*p_ref.shape, seed=29))
+    p_ref.backward(g)
+    xc = S.to_cl(x.detach().cuda(), dtype)
+    assert_close(S.from_cl(S.maxpool_fwd(xc)), p_ref, dtype, "maxpool")
+    prev = rnd(dtype, gen(n, c, d, h, w, seed=30))
+    gi = S.maxpool_bwd(xc, S.to_cl(g.cuda(), dtype), S.to_cl(prev.cuda(), dtype))
+    assert_close(S.from_cl(gi), rnd(dtype, x.grad + prev), dtype, "maxpool bwd (+=)")
+
+    y = rnd(dtype, gen(n, c, d, h, w, seed=31)).requires_grad_(True)
+    u_ref = F.interpolate(y, scale_factor=2, mode="trilinear", align_corners=True)
+    gu = rnd(dtype, gen(*u_ref.shape, seed=32))
+    u_ref.backward(gu)
+    assert_close(S.from_cl(S.upsample2_fwd(S.to_cl(y.detach().cuda(), dtype))), u_ref, dtype, "upsample")
+    assert_close(S.from_cl(S.upsample2_bwd(S.to_cl(gu.cuda(), dtype))), y.grad, dtype, "upsample bwd")
+
+
+def test_maxpool_tie_goes_to_first(S):
+    x = torch.zeros(1, 8, 2, 2, 2)
+    x[0, :, 0, 1, 1] = 1.0
+    x[0, :, 1, 0, 0] = 1.0        # tie: first in (z,y,x) scan order wins
+    xr = x.clone().requires_grad_(True)
+    F.max_pool3d(xr, 2, 2).backward(torch.ones(1, 8, 1, 1, 1))
+    gi = S.maxpool_bwd(S.to_cl(x.cuda(), "bf16"), S.to_cl(torch.ones(1, 8, 1, 1, 1).cuda(), "bf16"))
+    assert torch.equal(S.from_cl(gi).cpu(), xr.grad)
+
+
+def test_heads_forward_backward(S):
+    n, d, h, w = 2, 16, 8, 24
+    maps = [gen(n, d >> l, h >> l, w >> l, seed=33 + l).requires_grad_(True) for l in range(4)]
+    bias = gen(1, seed=40)
+    ref = bias.view(1, 1, 1, 1, 1) + maps[0].unsqueeze(1)
+    for l in range(1, 4):
+        ref = ref + F.interpolate(maps[l].unsqueeze(1), scale_factor=2 ** l, mode="trilinear", align_corners=True)
+    g = gen(*ref.shape, seed=41)
+    ref.backward(g)
+    pred = S.head_fwd([m.detach().cuda() for m in maps], bias.cuda())
+    assert_close(pred, ref, "fp32", "head fwd")
+    levels, gb = S.head_bwd(g.cuda(), 4)
+    for l in range(1, 4):
+        assert_close(levels[l], maps[l].grad, "fp32", f"head bwd level {l}")
+    assert abs(float(gb.cpu()) - float(g.sum())) < 1e-3
+
+
+def test_side_upsample(S):
+    side = gen(2, 3, 4, 5, 2, seed=42)
+    ref = F.interpolate(side.permute(0, 4, 1, 2, 3), scale_factor=4, mode="trilinear", align_corners=True)
+    assert_close(S.side_upsample(side.cuda(), 4), ref, "fp32", "side upsample")
+    assert_close(S.side_upsample(side.cuda(), 1), side.permute(0, 4, 1, 2, 3), "fp32", "side upsample x1")
+
+
+def test_losses_match_oracle(S):
+    import seunet_oracle as orc
+    import seunet_amd as A
+    g = torch.Generator().manual_seed(5)
+    logit = torch.randn(2, 1, 12, 12, 12, generator=g)
+    t = (torch.rand(2, 1, 12, 12, 12, generator=g) > 0.9).float()
+    wt = 1 + torch.rand(2, 1, 12, 12, 12, generator=g)
+    sk = t * (torch.rand(2, 1, 12, 12, 12, generator=g) > 0.5).float()
+    for name, args in (("dice_loss", (t,)), ("general_union_loss_lib", (t, wt)), ("atr_loss", (t, sk, wt))):
+        p = torch.sigmoid(logit).requires_grad_(True)
+        l_ref = getattr(orc, name)(p, *args)
+        l_ref.backward()
+        pg = torch.sigmoid(logit).cuda().requires_grad_(True)
+        l = getattr(A, name)(pg, *[a.cuda() for a in args])
+        (3.0 * l).backward()
+        assert abs(float(l) - float(l_ref)) < 2e-6, name
+        np.testing.assert_allclose(pg.grad.cpu().numpy() / 3.0, p.grad.numpy(), rtol=2e-4, atol=1e-9, err_msg=name)
+    for stage in (1, 2, 3):
+        a = logit.clone().requires_grad_(True)
+        b = (logit * 0.5 + 0.1).clone().requires_grad_(True)
+        l_ref = orc.stage_loss(stage, a, b, t, wt, sk)
+        l_ref.backward()
+        ag, bg = a.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+        l = A.fused_stage_loss(stage, ag, bg, t.cuda(), wt.cuda(), sk.cuda())
+        l.backward()
+        assert abs(float(l) - float(l_ref)) < 5e-6, stage
+        np.testing.assert_allclose(ag.grad.cpu().numpy(), a.grad.numpy(), rtol=3e-4, atol=1e-9)
+        np.testing.assert_allclose(bg.grad.cpu().numpy(), b.grad.numpy(), rtol=3e-4, atol=1e-9)
