@@ -69,27 +69,33 @@ int seunet_gate_epilogue_fwd(int dtype, const void* raw, const float* mean, cons
                              const float* w_se2, const float* w_side, const float* b_side, float slope, void* e_out,
                              float* side_out, float* level_map, int level_accumulate, const float* head_w,
                              const float* drop, int drop_stride, seunet_dims dims, seunet_stream_t s);
-/* backward pass A.  dxhat_out may alias g_e.  stat_partial: [n][slots][c][2]; pgrad_partial:
- * [n*slots][4c+4] = dw_se | dw_se2 | dw_side[2][c] | db_side[2] | dhead_w[2]. */
+/* backward, two recompute passes (dxhat itself is never stored; the loss gradient has a large common-mode
+ * part that the InstanceNorm backward cancels, so the per-(n,c) sums are taken in f64 and the centred
+ * result is rounded exactly once):
+ *   pass A (m1 == NULL): stat_partial f64 [n][slots][c][2] = sums of dxhat, dxhat*xhat; pgrad_partial f32
+ *                        [n*slots][4c+4] = dw_se | dw_se2 | dw_side[2][c] | db_side[2] | dhead_w[2]
+ *   seunet_stats_finalize_f64 -> m1, m2 ; seunet_pgrad_reduce -> parameter gradients
+ *   pass B (m1, m2 given): draw_out = rstd*(dxhat - m1 - xhat*m2), gradient w.r.t. the raw conv output
+ *                          (may alias g_e). */
 int seunet_gate_epilogue_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int c, const float* w_se,
                              const float* w_se2, const float* w_side, const float* b_side, float slope, const void* g_e,
                              const float* g_side, const float* g_level, const float* head_w, const float* drop,
-                             int drop_stride, void* dxhat_out, float* stat_partial, float* pgrad_partial,
-                             seunet_dims dims, seunet_stream_t s);
+                             int drop_stride, const float* m1, const float* m2, void* draw_out, double* stat_partial,
+                             float* pgrad_partial, seunet_dims dims, seunet_stream_t s);
+int seunet_stats_finalize_f64(const double* partial, int slots, int c, int n, long long count, float* out_a,
+                              float* out_b, seunet_stream_t s);
 int seunet_pgrad_reduce(const float* pgrad_partial, int records, int c, float* dw_se, float* dw_se2, float* dw_side,
                         float* db_side, float* dhead_w, seunet_stream_t s);
-/* InstanceNorm backward pass B, in place: dx <- rstd*(dx - m1 - xhat*m2) */
-int seunet_in_bwd(int dtype, void* dx, const void* raw, const float* mean, const float* rstd, const float* m1,
-                  const float* m2, int c, seunet_dims dims, seunet_stream_t s);
 
 /* ---- aggregation block: conv1x1 -> IN -> LeakyReLU (+ x-branch); SE_UNet.py:45-49,187,196,205 -------- */
 int seunet_cat_epilogue_fwd(int dtype, const void* raw, const float* mean, const float* rstd, const void* raw2,
                             const float* mean2, const float* rstd2, int c, float slope, void* out, seunet_dims dims,
                             seunet_stream_t s);
+/* same two-pass scheme; pass A (m1 == NULL) fills the f64 partials, pass B writes dx (may alias g_out) / dx2 */
 int seunet_cat_epilogue_bwd(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
                             const void* raw2, const float* mean2, const float* rstd2, int c, float slope,
-                            void* dxhat_out, void* dxhat2_out, float* stat_partial, float* stat_partial2,
-                            seunet_dims dims, seunet_stream_t s);
+                            const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, void* dx2,
+                            double* stat_partial, double* stat_partial2, seunet_dims dims, seunet_stream_t s);
 
 /* ---- nn.MaxPool3d(2,2) SE_UNet.py:131-133 ; nn.Upsample(x2 trilinear align_corners) :136-138 ---------- */
 int seunet_maxpool_fwd(int dtype, const void* in, int c, void* out, seunet_dims in_dims, seunet_stream_t s);
@@ -146,6 +152,12 @@ int seunet_net_forward(const seunet_net_desc* desc, const float* const* params, 
 int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
                         const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
                         void* workspace, size_t workspace_bytes, seunet_stream_t s);
+
+/* ---- opt-in timing of the launch groups inside seunet_net_forward/backward (HIP events on the caller's
+ * stream, thread local).  seunet_prof_report writes "tag<TAB>ms<TAB>count" lines and resets; it waits on
+ * the recorded events, so call it outside any timed region. */
+int seunet_prof_enable(int on);
+int seunet_prof_report(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

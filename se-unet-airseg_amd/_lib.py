@@ -49,11 +49,11 @@ PROTOTYPES = {
     "seunet_channel_stats": (_i, [_i, _vp, _i, _vp, Dims, _vp]),
     "seunet_stats_finalize": (_i, [_vp, _i, _i, _i, _ll, _f, _i, _vp, _vp, _vp]),
     "seunet_gate_epilogue_fwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _i, Dims, _vp]),
-    "seunet_gate_epilogue_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, Dims, _vp]),
+    "seunet_gate_epilogue_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),
+    "seunet_stats_finalize_f64": (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
     "seunet_pgrad_reduce": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "seunet_in_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, Dims, _vp]),
     "seunet_cat_epilogue_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, Dims, _vp]),
-    "seunet_cat_epilogue_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, Dims, _vp]),
+    "seunet_cat_epilogue_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),
     "seunet_maxpool_fwd": (_i, [_i, _vp, _i, _vp, Dims, _vp]),
     "seunet_maxpool_bwd": (_i, [_i, _vp, _vp, _i, _vp, _i, Dims, _vp]),
     "seunet_upsample2_fwd": (_i, [_i, _vp, _i, _vp, Dims, _vp]),
@@ -69,6 +69,8 @@ PROTOTYPES = {
     "seunet_net_param_info": (_i, [C.POINTER(NetDesc), _i, C.c_char_p, _i, _ip, _ip]),
     "seunet_net_workspace_bytes": (_sz, [C.POINTER(NetDesc)]),
     "seunet_net_forward": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "seunet_prof_enable": (_i, [_i]),
+    "seunet_prof_report": (_i, [C.c_char_p, _sz]),
     "seunet_net_backward": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _pp, _vp, _sz, _vp]),
 }
 

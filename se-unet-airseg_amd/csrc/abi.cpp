@@ -93,26 +93,25 @@ int seunet_gate_epilogue_fwd(int dtype, const void* raw, const float* mean, cons
 int seunet_gate_epilogue_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int c, const float* w_se,
                              const float* w_se2, const float* w_side, const float* b_side, float slope, const void* g_e,
                              const float* g_side, const float* g_level, const float* head_w, const float* drop, int drop_stride,
-                             void* dxhat_out, float* stat_partial, float* pgrad_partial, seunet_dims dims, seunet_stream_t s) {
-  SEUNET_CHECK(raw && mean && rstd && w_se && w_side && b_side && dxhat_out && stat_partial && pgrad_partial,
-               "gate_epilogue_bwd: null tensor");
+                             const float* m1, const float* m2, void* draw_out, double* stat_partial, float* pgrad_partial,
+                             seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(raw && mean && rstd && w_se && w_side && b_side, "gate_epilogue_bwd: null tensor");
   SEUNET_CHECK(!g_level || head_w, "gate_epilogue_bwd: g_level needs head_w");
   SseParams p{w_se, w_se2, w_side, b_side, slope};
   SseBwdIn g{g_e, g_side, g_level};
   SseHead h{nullptr, nullptr, 0, head_w, drop, drop_stride};
-  return launch_sse_bwd(dtype, raw, mean, rstd, c, p, g, h, dxhat_out, stat_partial, pgrad_partial, D(dims), S(s));
+  return launch_sse_bwd(dtype, raw, mean, rstd, c, p, g, h, m1, m2, draw_out, stat_partial, pgrad_partial, D(dims), S(s));
+}
+int seunet_stats_finalize_f64(const double* partial, int slots, int c, int n, long long count, float* out_a, float* out_b,
+                              seunet_stream_t s) {
+  SEUNET_CHECK(partial && out_a && out_b && slots >= 1 && count >= 1, "stats_finalize_f64: bad argument");
+  return launch_stats_finalize_f64(partial, slots, c, n, count, out_a, out_b, S(s));
 }
 int seunet_pgrad_reduce(const float* pgrad_partial, int records, int c, float* dw_se, float* dw_se2, float* dw_side,
                         float* db_side, float* dhead_w, seunet_stream_t s) {
   SEUNET_CHECK(pgrad_partial && records >= 1, "pgrad_reduce: bad argument");
   return launch_pgrad_reduce(pgrad_partial, records, c, dw_se, dw_se2, dw_side, db_side, dhead_w, S(s));
 }
-int seunet_in_bwd(int dtype, void* dx, const void* raw, const float* mean, const float* rstd, const float* m1, const float* m2,
-                  int c, seunet_dims dims, seunet_stream_t s) {
-  SEUNET_CHECK(dx && raw && mean && rstd && m1 && m2, "in_bwd: null tensor");
-  return launch_in_bwd_apply(dtype, dx, raw, mean, rstd, m1, m2, c, D(dims), S(s));
-}
-
 int seunet_cat_epilogue_fwd(int dtype, const void* raw, const float* mean, const float* rstd, const void* raw2,
                             const float* mean2, const float* rstd2, int c, float slope, void* out, seunet_dims dims,
                             seunet_stream_t s) {
@@ -120,11 +119,12 @@ int seunet_cat_epilogue_fwd(int dtype, const void* raw, const float* mean, const
   return launch_cat_fwd(dtype, raw, mean, rstd, raw2, mean2, rstd2, c, slope, out, D(dims), S(s));
 }
 int seunet_cat_epilogue_bwd(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
-                            const void* raw2, const float* mean2, const float* rstd2, int c, float slope, void* dxhat_out,
-                            void* dxhat2_out, float* stat_partial, float* stat_partial2, seunet_dims dims, seunet_stream_t s) {
-  SEUNET_CHECK(g_out && raw && mean && rstd && dxhat_out && stat_partial, "cat_epilogue_bwd: null tensor");
-  SEUNET_CHECK(!raw2 || (mean2 && rstd2 && dxhat2_out && stat_partial2), "cat_epilogue_bwd: second branch incomplete");
-  return launch_cat_bwd(dtype, g_out, raw, mean, rstd, raw2, mean2, rstd2, c, slope, dxhat_out, dxhat2_out, stat_partial,
+                            const void* raw2, const float* mean2, const float* rstd2, int c, float slope, const float* m1,
+                            const float* m2, const float* m1b, const float* m2b, void* dx, void* dx2, double* stat_partial,
+                            double* stat_partial2, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(g_out && raw && mean && rstd, "cat_epilogue_bwd: null tensor");
+  SEUNET_CHECK(!raw2 || (mean2 && rstd2), "cat_epilogue_bwd: second branch incomplete");
+  return launch_cat_bwd(dtype, g_out, raw, mean, rstd, raw2, mean2, rstd2, c, slope, m1, m2, m1b, m2b, dx, dx2, stat_partial,
                         stat_partial2, D(dims), S(s));
 }
 

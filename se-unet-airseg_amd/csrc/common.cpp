@@ -2,6 +2,8 @@
 #include "seunet_common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <map>
+#include <vector>
 
 namespace seunet {
 static thread_local std::string g_last_error;
@@ -18,4 +20,63 @@ int fail(const char* fmt, ...) {
   g_last_error = buf;
   return 1;
 }
+
+// ---- opt-in per-launch-group timing with HIP events on the caller's stream (bench.py's roofline) ------
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<std::pair<std::string, size_t>> marks;
+};
+static thread_local Prof g_prof;
+
+bool prof_on() { return g_prof.on; }
+
+void prof_mark(const char* tag, hipStream_t s) {
+  Prof& p = g_prof;
+  if (!p.on) return;
+  if (p.used == p.pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    p.pool.push_back(e);
+  }
+  hipEventRecord(p.pool[p.used], s);
+  p.marks.emplace_back(tag, p.used);
+  ++p.used;
+}
 }  // namespace seunet
+
+extern "C" int seunet_prof_enable(int on) {
+  seunet::g_prof.on = on != 0;
+  seunet::g_prof.used = 0;
+  seunet::g_prof.marks.clear();
+  return 0;
+}
+
+// Writes "tag\tmilliseconds\tcount\n" lines (time from each mark to the next one, summed per tag) and
+// resets the recorder.  Synchronises on the recorded events (call it outside the timed region).
+extern "C" int seunet_prof_report(char* buf, size_t cap) {
+  using namespace seunet;
+  Prof& p = g_prof;
+  std::map<std::string, std::pair<double, long>> agg;
+  if (!p.marks.empty()) {
+    if (hipEventSynchronize(p.pool[p.marks.back().second]) != hipSuccess) return fail("prof: event sync failed");
+    for (size_t i = 0; i + 1 < p.marks.size(); ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.pool[p.marks[i].second], p.pool[p.marks[i + 1].second]) != hipSuccess) continue;
+      auto& a = agg[p.marks[i].first];
+      a.first += ms;
+      a.second += 1;
+    }
+  }
+  std::string out;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s\t%.6f\t%ld\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  p.used = 0;
+  p.marks.clear();
+  if (buf && cap) snprintf(buf, cap, "%s", out.c_str());
+  return 0;
+}

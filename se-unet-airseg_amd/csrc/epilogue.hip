@@ -92,6 +92,31 @@ stats_finalize_kernel(const float* __restrict__ partial, int slots, int C, int N
   }
 }
 
+// backward statistics: f64 partial sums -> (sum/count, sumsq/count) as f32
+__global__ void __launch_bounds__(256)
+stats_finalize_f64_kernel(const double* __restrict__ partial, int slots, int C, int N, double inv_count,
+                          float* __restrict__ out_a, float* __restrict__ out_b) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= N * C) return;
+  const int n = idx / C, c = idx % C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = lane; p < slots; p += 64) {
+    const double* q = partial + (((long long)n * slots + p) * C + c) * 2;
+    s1 += q[0];
+    s2 += q[1];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  if (lane == 0) {
+    out_a[idx] = (float)(s1 * inv_count);
+    out_b[idx] = (float)(s2 * inv_count);
+  }
+}
+
 // ----------------------------------------------------------------------------------
 // gated block, forward
 // ----------------------------------------------------------------------------------
@@ -160,14 +185,19 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
 }
 
 // ----------------------------------------------------------------------------------
-// gated block, backward pass A: gradient w.r.t. the normalised activation (dxhat), its
-// InstanceNorm sums, and the gate / side / head parameter gradients
+// gated block, backward.  The gradient w.r.t. the normalised activation (dxhat) is recomputed from the
+// saved raw conv output in both passes and never stored:
+//   APPLY = false (pass A): per-(n,c) sums of dxhat and dxhat*xhat (f64: the loss gradient has a large
+//                           common-mode part that InstanceNorm's backward cancels, so f32 sums are not
+//                           enough) + the gate / side / head parameter gradients
+//   APPLY = true  (pass B): draw = rstd * (dxhat - m1 - xhat * m2), rounded once, stored over g_e
 // ----------------------------------------------------------------------------------
-template <typename T, int LPV, bool G2>
+template <typename T, int LPV, bool G2, bool APPLY>
 __global__ void __launch_bounds__(EPI_THREADS)
 sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
                const float* __restrict__ rstd, int C, SseParams p, SseBwdIn g, SseHead head,
-               T* dxhat_out, float* __restrict__ stat_partial,
+               const float* __restrict__ m1p, const float* __restrict__ m2p,
+               T* dxhat_out, double* __restrict__ stat_partial,
                float* __restrict__ pgrad_partial, long long V) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
@@ -190,9 +220,15 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     hw0 = head.head_w[0] * dr0;
     hw1 = head.head_w[1] * dr1;
   }
-  float sdx[8], sdxx[8], awse[8], awse2[8], aw20[8], aw21[8];
+  double sdx[8], sdxx[8];
+  float awse[8], awse2[8], aw20[8], aw21[8], am1[8], am2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sdx[j] = sdxx[j] = awse[j] = awse2[j] = aw20[j] = aw21[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) {
+    sdx[j] = sdxx[j] = 0.0;
+    awse[j] = awse2[j] = aw20[j] = aw21[j] = 0.f;
+    am1[j] = APPLY ? m1p[n * C + c0 + j] : 0.f;
+    am2[j] = APPLY ? m2p[n * C + c0 + j] : 0.f;
+  }
   float adb0 = 0.f, adb1 = 0.f, adh0 = 0.f, adh1 = 0.f;
 
   for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
@@ -226,7 +262,7 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       for (int j = 0; j < 8; ++j) { s0 += w20[j] * e[j]; s1 += w21[j] * e[j]; }
       s0 = group_sum<LPV>(s0) + b20;
       s1 = group_sum<LPV>(s1) + b21;
-      if (cg == 0) { adh0 += gl * dr0 * s0; adh1 += gl * dr1 * s1; }
+      if (!APPLY && cg == 0) { adh0 += gl * dr0 * s0; adh1 += gl * dr1 * s1; }
     } else if (g.g_side) {
       ds0 = g.g_side[vi * 2];
       ds1 = g.g_side[vi * 2 + 1];
@@ -264,25 +300,31 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       awse[j] += q1 * a[j];
       const float da = de[j] * g1 + q1 * wse[j];
       dxh[j] = da * (xh[j] > 0.f ? 1.f : slope);
-      sdx[j] += dxh[j];
-      sdxx[j] += dxh[j] * xh[j];
+      if (APPLY) {
+        dxh[j] = rs[j] * (dxh[j] - am1[j] - xh[j] * am2[j]);
+      } else {
+        sdx[j] += (double)dxh[j];
+        sdxx[j] += (double)dxh[j] * (double)xh[j];
+      }
     }
-    store8(dxhat_out + vi * C + c0, dxh);
+    if (APPLY) store8(dxhat_out + vi * C + c0, dxh);
   }
+  if (APPLY) return;
 
   // ---- block reduction (fixed order) ----
-  __shared__ float red[4][16][48];
+  __shared__ double redd[4][16][16];
+  __shared__ float red[4][16][32];
   __shared__ float reds[4][4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float r0 = stride_sum<LPV>(sdx[j]), r1 = stride_sum<LPV>(sdxx[j]);
+    const double r0 = stride_sum_d<LPV>(sdx[j]), r1 = stride_sum_d<LPV>(sdxx[j]);
     const float r2 = stride_sum<LPV>(awse[j]), r3 = stride_sum<LPV>(awse2[j]);
     const float r4 = stride_sum<LPV>(aw20[j]), r5 = stride_sum<LPV>(aw21[j]);
     if (lane < LPV) {
-      red[wave][lane][j] = r0;      red[wave][lane][8 + j] = r1;
-      red[wave][lane][16 + j] = r2; red[wave][lane][24 + j] = r3;
-      red[wave][lane][32 + j] = r4; red[wave][lane][40 + j] = r5;
+      redd[wave][lane][j] = r0;     redd[wave][lane][8 + j] = r1;
+      red[wave][lane][j] = r2;      red[wave][lane][8 + j] = r3;
+      red[wave][lane][16 + j] = r4; red[wave][lane][24 + j] = r5;
     }
   }
   {
@@ -293,18 +335,15 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   __syncthreads();
   const long long rec = (long long)n * P + blockIdx.x;
   float* pg = pgrad_partial + rec * (4 * C + 4);
-  for (int i = threadIdx.x; i < LPV * 48; i += EPI_THREADS) {
-    const int gq = i / 48, k = i % 48;
+  for (int i = threadIdx.x; i < LPV * 16; i += EPI_THREADS) {
+    const int gq = i / 16, k = i % 16;
+    const double tot = ((redd[0][gq][k] + redd[1][gq][k]) + redd[2][gq][k]) + redd[3][gq][k];
+    stat_partial[(rec * C + gq * 8 + (k & 7)) * 2 + (k >> 3)] = tot;
+  }
+  for (int i = threadIdx.x; i < LPV * 32; i += EPI_THREADS) {
+    const int gq = i / 32, k = i % 32;
     const float tot = ((red[0][gq][k] + red[1][gq][k]) + red[2][gq][k]) + red[3][gq][k];
-    const int c = gq * 8 + (k & 7);
-    switch (k >> 3) {
-      case 0: stat_partial[(rec * C + c) * 2] = tot; break;
-      case 1: stat_partial[(rec * C + c) * 2 + 1] = tot; break;
-      case 2: pg[c] = tot; break;
-      case 3: pg[C + c] = tot; break;
-      case 4: pg[2 * C + c] = tot; break;
-      default: pg[3 * C + c] = tot; break;
-    }
+    pg[(k >> 3) * C + gq * 8 + (k & 7)] = tot;
   }
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
@@ -330,38 +369,6 @@ pgrad_reduce_kernel(const float* __restrict__ pg, int records, int C, float* dw_
   else if (k < 4 * C) { if (dw_side) dw_side[k - 2 * C] = v; }
   else if (k < 4 * C + 2) { if (db_side) db_side[k - 4 * C] = v; }
   else { if (dhead_w) dhead_w[k - 4 * C - 2] = v; }
-}
-
-// ----------------------------------------------------------------------------------
-// InstanceNorm backward, pass B:  draw = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat))
-// ----------------------------------------------------------------------------------
-template <typename T, int LPV>
-__global__ void __launch_bounds__(EPI_THREADS)
-in_bwd_apply_kernel(T* __restrict__ dx, const T* __restrict__ raw, const float* __restrict__ mean,
-                    const float* __restrict__ rstd, const float* __restrict__ m1,
-                    const float* __restrict__ m2, int C, long long V) {
-  const int n = blockIdx.y, P = gridDim.x;
-  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
-  constexpr int VPB = EPI_THREADS / LPV;
-  const int c0 = cg * 8;
-  float mu[8], rs[8], a1[8], a2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
-    a1[j] = m1[n * C + c0 + j];   a2[j] = m2[n * C + c0 + j];
-  }
-  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
-    const long long o = ((long long)n * V + v) * C + c0;
-    float d[8], x[8];
-    load8(dx + o, d);
-    load8(raw + o, x);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xh = (x[j] - mu[j]) * rs[j];
-      d[j] = rs[j] * (d[j] - a1[j] - xh * a2[j]);
-    }
-    store8(dx + o, d);
-  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -405,25 +412,34 @@ cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   }
 }
 
-template <typename T, int LPV, bool TWO>
+// APPLY = false: per-(n,c) f64 sums of dxhat, dxhat*xhat for one or two branches (nothing stored)
+// APPLY = true : draw = rstd * (dxhat - m1 - xhat * m2) for each branch (dxhat_out may alias g_out)
+template <typename T, int LPV, bool TWO, bool APPLY>
 __global__ void __launch_bounds__(EPI_THREADS)
 cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
                const float* __restrict__ mean, const float* __restrict__ rstd,
                const T* __restrict__ raw2, const float* __restrict__ mean2,
-               const float* __restrict__ rstd2, int C, float slope, T* dxhat_out,
-               T* dxhat2_out, float* __restrict__ stat_partial,
-               float* __restrict__ stat_partial2, long long V) {
+               const float* __restrict__ rstd2, int C, float slope,
+               const float* __restrict__ m1p, const float* __restrict__ m2p,
+               const float* __restrict__ m1bp, const float* __restrict__ m2bp, T* dxhat_out,
+               T* dxhat2_out, double* __restrict__ stat_partial,
+               double* __restrict__ stat_partial2, long long V) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
   constexpr int VPB = EPI_THREADS / LPV;
   const int c0 = cg * 8;
-  float mu[8], rs[8], mu2[8], rs2[8], s[4][8];
+  float mu[8], rs[8], mu2[8], rs2[8], a1[8], a2[8], b1[8], b2[8];
+  double s[4][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
     mu2[j] = TWO ? mean2[n * C + c0 + j] : 0.f;
     rs2[j] = TWO ? rstd2[n * C + c0 + j] : 0.f;
-    s[0][j] = s[1][j] = s[2][j] = s[3][j] = 0.f;
+    a1[j] = APPLY ? m1p[n * C + c0 + j] : 0.f;
+    a2[j] = APPLY ? m2p[n * C + c0 + j] : 0.f;
+    b1[j] = (APPLY && TWO) ? m1bp[n * C + c0 + j] : 0.f;
+    b2[j] = (APPLY && TWO) ? m2bp[n * C + c0 + j] : 0.f;
+    s[0][j] = s[1][j] = s[2][j] = s[3][j] = 0.0;
   }
   for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
     const long long o = ((long long)n * V + v) * C + c0;
@@ -434,8 +450,8 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
     for (int j = 0; j < 8; ++j) {
       const float xh = (x[j] - mu[j]) * rs[j];
       d[j] = gy[j] * (xh > 0.f ? 1.f : slope);
-      s[0][j] += d[j];
-      s[1][j] += d[j] * xh;
+      if (APPLY) d[j] = rs[j] * (d[j] - a1[j] - xh * a2[j]);
+      else { s[0][j] += (double)d[j]; s[1][j] += (double)d[j] * (double)xh; }
     }
     if (TWO) {
       float d2[8];
@@ -444,27 +460,28 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
       for (int j = 0; j < 8; ++j) {
         const float xh = (x[j] - mu2[j]) * rs2[j];
         d2[j] = gy[j] * (xh > 0.f ? 1.f : slope);
-        s[2][j] += d2[j];
-        s[3][j] += d2[j] * xh;
+        if (APPLY) d2[j] = rs2[j] * (d2[j] - b1[j] - xh * b2[j]);
+        else { s[2][j] += (double)d2[j]; s[3][j] += (double)d2[j] * (double)xh; }
       }
-      store8(dxhat2_out + o, d2);
+      if (APPLY) store8(dxhat2_out + o, d2);
     }
-    store8(dxhat_out + o, d);  // may alias g_out (same element, read before write)
+    if (APPLY) store8(dxhat_out + o, d);  // may alias g_out (same element, read before write)
   }
-  __shared__ float red[4][16][32];
+  if (APPLY) return;
+  __shared__ double red[4][16][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float r = stride_sum<LPV>(s[q][j]);
+      const double r = stride_sum_d<LPV>(s[q][j]);
       if (lane < LPV) red[wave][lane][q * 8 + j] = r;
     }
   __syncthreads();
   const long long rec = (long long)n * P + blockIdx.x;
   for (int i = threadIdx.x; i < LPV * 32; i += EPI_THREADS) {
     const int gq = i / 32, k = i % 32, q = k >> 3;
-    const float tot = ((red[0][gq][k] + red[1][gq][k]) + red[2][gq][k]) + red[3][gq][k];
+    const double tot = ((red[0][gq][k] + red[1][gq][k]) + red[2][gq][k]) + red[3][gq][k];
     const int c = gq * 8 + (k & 7);
     if (q < 2) stat_partial[(rec * C + c) * 2 + q] = tot;
     else if (TWO) stat_partial2[(rec * C + c) * 2 + (q - 2)] = tot;
@@ -529,43 +546,46 @@ int launch_sse_fwd(int dtype, const void* raw, const float* mean, const float* r
   return 0;
 }
 
-int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
-                   const SseParams& p, const SseBwdIn& g, const SseHead& head, void* dxhat_out,
-                   float* stat_partial, float* pgrad_partial, Dims d, hipStream_t s) {
-  if (int e = check_c(C)) return e;
-  dim3 grid(epi_partials(d), d.N);
+int launch_stats_finalize_f64(const double* partial, int slots, int C, int N, long long count, float* out_a,
+                              float* out_b, hipStream_t s) {
+  stats_finalize_f64_kernel<<<cdiv(N * C, 4), 256, 0, s>>>(partial, slots, C, N, 1.0 / (double)count, out_a, out_b);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, bool APPLY>
+static int sse_bwd_t(const void* raw, const float* mean, const float* rstd, int C, const SseParams& p, const SseBwdIn& g,
+                     const SseHead& head, const float* m1, const float* m2, void* out, double* stat_partial,
+                     float* pgrad_partial, Dims d, hipStream_t s) {
+  dim3 grid(epi_partials(d) * (APPLY ? 4 : 1), d.N);
   const bool g2 = p.w_se2 != nullptr;
   SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16) {
-      if (g2) sse_bwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, g, head, (bf16_t*)dxhat_out, stat_partial, pgrad_partial, d.vox());
-      else sse_bwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, g, head, (bf16_t*)dxhat_out, stat_partial, pgrad_partial, d.vox());
-    } else {
-      if (g2) sse_bwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, g, head, (float*)dxhat_out, stat_partial, pgrad_partial, d.vox());
-      else sse_bwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, g, head, (float*)dxhat_out, stat_partial, pgrad_partial, d.vox());
-    }
+    if (g2) sse_bwd_kernel<T, LPV, true, APPLY><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, C, p, g, head, m1, m2, (T*)out, stat_partial, pgrad_partial, d.vox());
+    else sse_bwd_kernel<T, LPV, false, APPLY><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, C, p, g, head, m1, m2, (T*)out, stat_partial, pgrad_partial, d.vox());
   });
   SEUNET_LAUNCH_CHECK();
   return 0;
+}
+
+// m1 == nullptr: pass A (sums + parameter-gradient records); otherwise pass B (writes draw_out)
+int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
+                   const SseParams& p, const SseBwdIn& g, const SseHead& head, const float* m1, const float* m2,
+                   void* draw_out, double* stat_partial, float* pgrad_partial, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  if (m1 == nullptr) {
+    SEUNET_CHECK(stat_partial && pgrad_partial, "gate_epilogue_bwd pass A needs the partial buffers");
+    return dtype == SEUNET_BF16 ? sse_bwd_t<bf16_t, false>(raw, mean, rstd, C, p, g, head, nullptr, nullptr, nullptr, stat_partial, pgrad_partial, d, s)
+                                : sse_bwd_t<float, false>(raw, mean, rstd, C, p, g, head, nullptr, nullptr, nullptr, stat_partial, pgrad_partial, d, s);
+  }
+  SEUNET_CHECK(m2 && draw_out, "gate_epilogue_bwd pass B needs m2 and the output tensor");
+  return dtype == SEUNET_BF16 ? sse_bwd_t<bf16_t, true>(raw, mean, rstd, C, p, g, head, m1, m2, draw_out, nullptr, nullptr, d, s)
+                              : sse_bwd_t<float, true>(raw, mean, rstd, C, p, g, head, m1, m2, draw_out, nullptr, nullptr, d, s);
 }
 
 int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* dw_se, float* dw_se2,
                         float* dw_side, float* db_side, float* dhead_w, hipStream_t s) {
   pgrad_reduce_kernel<<<cdiv(4 * C + 4, 4), 256, 0, s>>>(pgrad_partial, records, C, dw_se, dw_se2,
                                                         dw_side, db_side, dhead_w);
-  SEUNET_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_in_bwd_apply(int dtype, void* dx, const void* raw, const float* mean, const float* rstd,
-                        const float* m1, const float* m2, int C, Dims d, hipStream_t s) {
-  if (int e = check_c(C)) return e;
-  dim3 grid(epi_partials(d) * 4, d.N);
-  SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16)
-      in_bwd_apply_kernel<bf16_t, LPV><<<grid, EPI_THREADS, 0, s>>>((bf16_t*)dx, (const bf16_t*)raw, mean, rstd, m1, m2, C, d.vox());
-    else
-      in_bwd_apply_kernel<float, LPV><<<grid, EPI_THREADS, 0, s>>>((float*)dx, (const float*)raw, mean, rstd, m1, m2, C, d.vox());
-  });
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -589,24 +609,34 @@ int launch_cat_fwd(int dtype, const void* raw, const float* mean, const float* r
   return 0;
 }
 
-int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
-                   const void* raw2, const float* mean2, const float* rstd2, int C, float slope,
-                   void* dxhat_out, void* dxhat2_out, float* stat_partial, float* stat_partial2, Dims d,
-                   hipStream_t s) {
-  if (int e = check_c(C)) return e;
-  dim3 grid(epi_partials(d), d.N);
+template <typename T, bool APPLY>
+static int cat_bwd_t(const void* g_out, const void* raw, const float* mean, const float* rstd, const void* raw2,
+                     const float* mean2, const float* rstd2, int C, float slope, const float* m1, const float* m2,
+                     const float* m1b, const float* m2b, void* dx, void* dx2, double* st, double* st2, Dims d, hipStream_t s) {
+  dim3 grid(epi_partials(d) * (APPLY ? 4 : 1), d.N);
   const bool two = raw2 != nullptr;
   SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16) {
-      if (two) cat_bwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)raw2, mean2, rstd2, C, slope, (bf16_t*)dxhat_out, (bf16_t*)dxhat2_out, stat_partial, stat_partial2, d.vox());
-      else cat_bwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (bf16_t*)dxhat_out, nullptr, stat_partial, nullptr, d.vox());
-    } else {
-      if (two) cat_bwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)raw2, mean2, rstd2, C, slope, (float*)dxhat_out, (float*)dxhat2_out, stat_partial, stat_partial2, d.vox());
-      else cat_bwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (float*)dxhat_out, nullptr, stat_partial, nullptr, d.vox());
-    }
+    if (two) cat_bwd_kernel<T, LPV, true, APPLY><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (T*)dx, (T*)dx2, st, st2, d.vox());
+    else cat_bwd_kernel<T, LPV, false, APPLY><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, m1, m2, nullptr, nullptr, (T*)dx, nullptr, st, nullptr, d.vox());
   });
   SEUNET_LAUNCH_CHECK();
   return 0;
+}
+
+// m1 == nullptr: pass A (f64 sums into stat_partial[2]); otherwise pass B (writes draw into dx / dx2)
+int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                   const void* raw2, const float* mean2, const float* rstd2, int C, float slope, const float* m1,
+                   const float* m2, const float* m1b, const float* m2b, void* dx, void* dx2, double* stat_partial,
+                   double* stat_partial2, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  if (m1 == nullptr) {
+    SEUNET_CHECK(stat_partial && (!raw2 || stat_partial2), "cat_epilogue_bwd pass A needs the partial buffers");
+    return dtype == SEUNET_BF16 ? cat_bwd_t<bf16_t, false>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d, s)
+                                : cat_bwd_t<float, false>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d, s);
+  }
+  SEUNET_CHECK(m2 && dx && (!raw2 || (m1b && m2b && dx2)), "cat_epilogue_bwd pass B: missing argument");
+  return dtype == SEUNET_BF16 ? cat_bwd_t<bf16_t, true>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, dx, dx2, nullptr, nullptr, d, s)
+                              : cat_bwd_t<float, true>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, dx, dx2, nullptr, nullptr, d, s);
 }
 
 }  // namespace seunet

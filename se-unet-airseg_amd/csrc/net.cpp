@@ -202,7 +202,7 @@ struct Plan {
         lvl[h][l] = take((size_t)d.batch * dims[l].vox() * 4);
         glvl[h][l] = take((size_t)d.batch * dims[l].vox() * 4);
       }
-    const size_t stat_bytes = (size_t)d.batch * slots_max * cmax * 2 * 4;
+    const size_t stat_bytes = (size_t)d.batch * slots_max * cmax * 2 * 8;   // f32 forward / f64 backward partials
     stats = take(stat_bytes);
     stats2 = take(stat_bytes);
     pgrad = take((size_t)d.batch * slots_max * (4 * cmax + 4) * 4);
@@ -226,8 +226,10 @@ struct Exec {
   const float* const* params = nullptr;
   hipStream_t s = nullptr;
 
+  void mark(const std::string& tag) const { if (prof_on()) prof_mark(tag.c_str(), s); }
   void* at(size_t off) const { return ws + off; }
   float* fat(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+  double* dat(size_t off) const { return reinterpret_cast<double*>(ws + off); }
   const float* P(const std::string& name) const {
     const int i = find_param(reg, name);
     return i < 0 ? nullptr : params[i];
@@ -255,20 +257,25 @@ struct Exec {
   }
 
   // conv (+ InstanceNorm statistics) of one block: raw <- conv(src), (mean, rstd) <- stats(raw)
-  int conv_and_stats(int taps, int dil, const SrcList& src, int cin, const float* w, const float* bias, size_t wp_off,
+  int conv_and_stats(const std::string& nm, int taps, int dil, const SrcList& src, int cin, const float* w, const float* bias, size_t wp_off,
                      size_t raw_off, int cout, size_t mean_off, size_t rstd_off, const Dims& dm) {
     DstList dst{};
     dst.n = 1; dst.ptr[0] = at(raw_off); dst.C[0] = cout; dst.acc[0] = 0;
     int slots;
     if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
+      mark("conv_fwd:" + nm);
       if (int e = launch_conv_naive(p.d.dtype, taps, dil, src, cin, w, 0, bias, dst, dm, s)) return e;
+      mark("stats");
       if (int e = launch_channel_stats(p.d.dtype, at(raw_off), cout, fat(p.stats), dm, s)) return e;
       slots = epi_partials(dm);
     } else {
+      mark("pack_w");
       if (int e = launch_conv_pack_weights(p.d.dtype, w, taps, cin, cout, 0, at(wp_off), s)) return e;
+      mark("conv_fwd:" + nm);
       if (int e = launch_conv_igemm(p.d.dtype, taps, dil, src, cin, at(wp_off), bias, dst, fat(p.stats), dm, s)) return e;
       slots = conv_stats_tiles(dm);
     }
+    mark("stats");
     return launch_stats_finalize(fat(p.stats), slots, cout, dm.N, dm.vox(), p.d.eps, 0, fat(mean_off), fat(rstd_off), s);
   }
 
@@ -296,6 +303,7 @@ struct Exec {
   }
 
   int forward(const float* x, const float* drop1, const float* drop2, float* pred0, float* pred1) {
+    mark("pack_input");
     if (int e = launch_pack_input(p.d.dtype, x, p.d.in_channel, at(p.feat[T_X0]), p.dims[0], s)) return e;
     bool lvl_written[2][4] = {{false, false, false, false}, {false, false, false, false}};
     for (int i = 0; i < kNumOps; ++i) {
@@ -303,27 +311,31 @@ struct Exec {
       const OpRes& r = p.op[i];
       const std::string n = o.name;
       if (o.kind == OP_POOL) {
+        mark("pool_fwd");
         if (int e = launch_maxpool_fwd(p.d.dtype, at(p.feat[o.src[0]]), p.C[o.src[0]], at(p.feat[o.dst]), p.dims[kT[o.src[0]].level], s)) return e;
       } else if (o.kind == OP_UP) {
+        mark("up_fwd");
         if (int e = launch_upsample2_fwd(p.d.dtype, at(p.feat[o.src[0]]), p.C[o.src[0]], at(p.feat[o.dst]), p.dims[kT[o.src[0]].level], s)) return e;
       } else if (o.kind == OP_GATED) {
         const int lv = kT[o.dst].level;
-        if (int e = conv_and_stats(27, o.dil, srcs(o), r.cin, P(n + ".conv1.weight"), P(n + ".conv1.bias"), r.wp_f, r.raw,
+        if (int e = conv_and_stats(n, 27, o.dil, srcs(o), r.cin, P(n + ".conv1.weight"), P(n + ".conv1.bias"), r.wp_f, r.raw,
                                    r.cout, r.mean, r.rstd, p.dims[lv])) return e;
         const SseHead hd = sse_head(o, drop1, drop2, !lvl_written[o.head][lv]);
         lvl_written[o.head][lv] = true;
+        mark("epi_fwd:" + n);
         if (int e = launch_sse_fwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), at(p.feat[o.dst]), hd,
                                    p.dims[lv], s)) return e;
       } else {  // OP_CAT
         const int lv = kT[o.dst].level;
-        if (int e = conv_and_stats(1, 1, srcs(o), r.cin, P(n + ".conv1.weight"), nullptr, r.wp_f, r.raw, r.cout, r.mean,
+        if (int e = conv_and_stats(n, 1, 1, srcs(o), r.cin, P(n + ".conv1.weight"), nullptr, r.wp_f, r.raw, r.cout, r.mean,
                                    r.rstd, p.dims[lv])) return e;
         if (o.xname) {
           SrcList xs{};
           xs.n = 1; xs.ptr[0] = at(p.feat[o.xsrc]); xs.C[0] = 8;
-          if (int e = conv_and_stats(1, 1, xs, p.d.in_channel, P(std::string(o.xname) + ".conv1.weight"), nullptr, r.wp_x,
+          if (int e = conv_and_stats(o.xname, 1, 1, xs, p.d.in_channel, P(std::string(o.xname) + ".conv1.weight"), nullptr, r.wp_x,
                                      r.raw2, r.cout, r.mean2, r.rstd2, p.dims[lv])) return e;
         }
+        mark("cat_fwd:" + n);
         if (int e = launch_cat_fwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), o.xname ? at(r.raw2) : nullptr,
                                    o.xname ? fat(r.mean2) : nullptr, o.xname ? fat(r.rstd2) : nullptr, r.cout,
                                    p.d.negative_slope, at(p.feat[o.dst]), p.dims[lv], s)) return e;
@@ -331,8 +343,11 @@ struct Exec {
     }
     const float* enc[4] = {fat(p.lvl[0][0]), fat(p.lvl[0][1]), fat(p.lvl[0][2]), fat(p.lvl[0][3])};
     const float* dec[3] = {fat(p.lvl[1][0]), fat(p.lvl[1][1]), fat(p.lvl[1][2])};
+    mark("head_fwd");
     if (int e = launch_head_fwd(enc, 4, P("dc0_0.bias"), pred0, p.dims[0], s)) return e;
-    return launch_head_fwd(dec, 3, P("dc0_1.bias"), pred1, p.dims[0], s);
+    if (int e = launch_head_fwd(dec, 3, P("dc0_1.bias"), pred1, p.dims[0], s)) return e;
+    mark("outside");
+    return 0;
   }
 
   // gradient w.r.t. the raw conv output is in grad[dst]; produce weight gradient and input gradients
@@ -343,6 +358,7 @@ struct Exec {
     const std::string n = o.name;
     const int wi = find_param(reg, n + ".conv1.weight");
     if (grads[wi]) {
+      mark("wgrad:" + n);
       if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
         if (int e = launch_wgrad_naive(p.d.dtype, r.taps, o.dil, x, r.cin, at(p.grad[o.dst]), r.cout, grads[wi], p.dims[lv], s)) return e;
       } else {
@@ -363,6 +379,7 @@ struct Exec {
       if (!is_input(t)) written[t] = true;
     }
     const float* w = P(n + ".conv1.weight");
+    mark("dgrad:" + n);
     if (p.d.conv_impl == SEUNET_CONV_NAIVE)
       return launch_conv_naive(p.d.dtype, r.taps, o.dil, gsrc, r.cout, w, 1, nullptr, gd, p.dims[lv], s);
     if (int e = launch_conv_pack_weights(p.d.dtype, w, r.taps, r.cin, r.cout, 1, at(r.wp_d), s)) return e;
@@ -374,6 +391,7 @@ struct Exec {
     for (int t = 0; t < T_COUNT; ++t) written[t] = false;
     // heads: level gradients = transposed interpolation of the logit gradients
     {
+      mark("head_bwd");
       float* ge[4] = {nullptr, fat(p.glvl[0][1]), fat(p.glvl[0][2]), fat(p.glvl[0][3])};
       float* gd[4] = {nullptr, fat(p.glvl[1][1]), fat(p.glvl[1][2]), nullptr};
       if (int e = launch_head_bwd(g_pred0, ge, 4, fat(p.head_tmp), grads[find_param(reg, "dc0_0.bias")], p.dims[0], s)) return e;
@@ -387,6 +405,7 @@ struct Exec {
         const int t = o.src[0];
         if (is_input(t)) continue;
         SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
+        mark(o.kind == OP_POOL ? "pool_bwd" : "up_bwd");
         if (o.kind == OP_POOL) {
           if (int e = launch_maxpool_bwd(p.d.dtype, at(p.feat[t]), at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
                                          p.dims[kT[t].level], s)) return e;
@@ -406,34 +425,45 @@ struct Exec {
         g.g_side = nullptr;
         g.g_level = lv == 0 ? (o.head == 0 ? g_pred0 : g_pred1) : fat(p.glvl[o.head][lv]);
         const SseHead hd = sse_head(o, drop1, drop2, false);
-        if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd,
-                                   at(p.grad[o.dst]), fat(p.stats), fat(p.pgrad), dm, s)) return e;
-        written[o.dst] = true;
-        if (int e = launch_stats_finalize(fat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
+        mark("epi_bwd:" + n);   // pass A: f64 sums + parameter-gradient records
+        if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd, nullptr, nullptr,
+                                   nullptr, dat(p.stats), fat(p.pgrad), dm, s)) return e;
+        mark("stats");
+        if (int e = launch_stats_finalize_f64(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1), fat(p.m2), s)) return e;
         float* g_head = grads[find_param(reg, o.head == 0 ? "dc0_0.weight" : "dc0_1.weight")];
         const int i_se2 = o.gates == 2 ? find_param(reg, n + ".conv_se2.weight") : -1;
         if (int e = launch_pgrad_reduce(fat(p.pgrad), dm.N * P_slots, r.cout, grads[find_param(reg, n + ".conv_se.weight")],
                                         i_se2 >= 0 ? grads[i_se2] : nullptr, grads[find_param(reg, n + ".conv2.weight")],
                                         grads[find_param(reg, n + ".conv2.bias")], g_head ? g_head + 2 * o.m : nullptr, s)) return e;
-        if (int e = launch_in_bwd_apply(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), fat(p.m1), fat(p.m2),
-                                        r.cout, dm, s)) return e;
+        mark("in_bwd:" + n);    // pass B: recompute dxhat, apply the InstanceNorm backward, store draw over g_e
+        if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd, fat(p.m1), fat(p.m2),
+                                   at(p.grad[o.dst]), nullptr, nullptr, dm, s)) return e;
+        written[o.dst] = true;
         // conv1.bias feeds an affine-less InstanceNorm: its gradient is identically zero
         if (float* gb = grads[find_param(reg, n + ".conv1.bias")]) SEUNET_HIP(hipMemsetAsync(gb, 0, (size_t)r.cout * 4, s));
         if (int e = conv_backward(i, srcs(o), grads, written)) return e;
       } else {  // OP_CAT
         SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
-        if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), o.xname ? at(r.raw2) : nullptr,
-                                   o.xname ? fat(r.mean2) : nullptr, o.xname ? fat(r.rstd2) : nullptr, r.cout, p.d.negative_slope,
-                                   at(p.grad[o.dst]), o.xname ? at(p.gx) : nullptr, fat(p.stats), fat(p.stats2), dm, s)) return e;
-        if (int e = launch_stats_finalize(fat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
-        if (int e = launch_in_bwd_apply(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), fat(p.m1), fat(p.m2),
-                                        r.cout, dm, s)) return e;
+        mark("cat_bwd:" + n);   // pass A
+        const void* r2 = o.xname ? at(r.raw2) : nullptr;
+        const float* mu2 = o.xname ? fat(r.mean2) : nullptr;
+        const float* rs2 = o.xname ? fat(r.rstd2) : nullptr;
+        if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
+                                   p.d.negative_slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dat(p.stats),
+                                   dat(p.stats2), dm, s)) return e;
+        mark("stats");
+        if (int e = launch_stats_finalize_f64(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1), fat(p.m2), s)) return e;
+        if (o.xname)
+          if (int e = launch_stats_finalize_f64(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1b), fat(p.m2b), s)) return e;
+        mark("in_bwd:" + n);    // pass B
+        if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
+                                   p.d.negative_slope, fat(p.m1), fat(p.m2), o.xname ? fat(p.m1b) : nullptr,
+                                   o.xname ? fat(p.m2b) : nullptr, at(p.grad[o.dst]), o.xname ? at(p.gx) : nullptr, nullptr, nullptr,
+                                   dm, s)) return e;
         if (o.xname) {
-          if (int e = launch_stats_finalize(fat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
-          if (int e = launch_in_bwd_apply(p.d.dtype, at(p.gx), at(r.raw2), fat(r.mean2), fat(r.rstd2), fat(p.m1b), fat(p.m2b),
-                                          r.cout, dm, s)) return e;
           const int xi = find_param(reg, std::string(o.xname) + ".conv1.weight");
           if (grads[xi]) {
+            mark(std::string("wgrad:") + o.xname);
             SrcList xs{};
             xs.n = 1; xs.ptr[0] = at(p.feat[o.xsrc]); xs.C[0] = 8;
             if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
@@ -447,6 +477,7 @@ struct Exec {
         if (int e = conv_backward(i, srcs(o), grads, written)) return e;
       }
     }
+    mark("outside");
     return 0;
   }
 };

@@ -17,6 +17,8 @@ namespace seunet {
 void set_error(const std::string& msg);
 const char* get_error();
 int fail(const char* fmt, ...);
+bool prof_on();
+void prof_mark(const char* tag, hipStream_t s);   // no-op unless seunet_prof_enable(1)
 
 #define SEUNET_CHECK(cond, ...)                       \
   do {                                                \
@@ -117,6 +119,11 @@ template <int LPV> __device__ __forceinline__ float stride_sum(float v) {
   for (int off = 32; off >= LPV; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+template <int LPV> __device__ __forceinline__ double stride_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= LPV; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 #endif  // __HIPCC__
 
@@ -175,22 +182,24 @@ struct SseBwdIn {
 };
 // partial parameter-gradient record per (sample, slot):  4*C + 4 floats
 //   [0,C) dw_se  [C,2C) dw_se2  [2C,4C) dw_side[2][C]  [4C,4C+2) db_side  [4C+2,4C+4) dhead_w
+// m1 == nullptr: pass A (f64 stat sums + parameter-gradient records); else pass B (writes draw_out, may alias g_e)
 int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
-                   const SseParams& p, const SseBwdIn& g, const SseHead& head, void* dxhat_out,
-                   float* stat_partial, float* pgrad_partial, Dims d, hipStream_t s);
+                   const SseParams& p, const SseBwdIn& g, const SseHead& head, const float* m1,
+                   const float* m2, void* draw_out, double* stat_partial, float* pgrad_partial,
+                   Dims d, hipStream_t s);
+int launch_stats_finalize_f64(const double* partial, int slots, int C, int N, long long count,
+                              float* out_a, float* out_b, hipStream_t s);
 int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* dw_se,
                         float* dw_se2, float* dw_side, float* db_side, float* dhead_w,
-                        hipStream_t s);
-int launch_in_bwd_apply(int dtype, void* dxhat_inout, const void* raw, const float* mean,
-                        const float* rstd, const float* m1, const float* m2, int C, Dims d,
                         hipStream_t s);
 int launch_cat_fwd(int dtype, const void* raw, const float* mean, const float* rstd,
                    const void* raw2, const float* mean2, const float* rstd2, int C, float slope,
                    void* out, Dims d, hipStream_t s);
 int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* mean,
                    const float* rstd, const void* raw2, const float* mean2, const float* rstd2,
-                   int C, float slope, void* dxhat_out, void* dxhat2_out, float* stat_partial,
-                   float* stat_partial2, Dims d, hipStream_t s);
+                   int C, float slope, const float* m1, const float* m2, const float* m1b,
+                   const float* m2b, void* dx, void* dx2, double* stat_partial,
+                   double* stat_partial2, Dims d, hipStream_t s);
 
 // pooling / interpolation / heads (resample.hip)
 int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);

@@ -148,31 +148,43 @@ def gate_epilogue_fwd(raw, mean, rstd, w_se, w_se2, w_side, b_side, slope=0.01, 
     return e, side
 
 
+def stats_finalize_f64(partial: torch.Tensor, slots: int, count: int):
+    n, _, c, _ = partial.shape
+    a = torch.empty((n, c), dtype=torch.float32, device=partial.device)
+    b = torch.empty_like(a)
+    _lib.check(_lib.load().seunet_stats_finalize_f64(partial.data_ptr(), slots, c, n, count, a.data_ptr(), b.data_ptr(), _s()),
+               "stats_finalize_f64")
+    return a, b
+
+
 def gate_epilogue_bwd(raw, mean, rstd, w_se, w_se2, w_side, b_side, slope=0.01, g_e=None, g_side=None, g_level=None,
                       head_w=None, drop=None, drop_stride=0):
-    """Returns dict with draw (gradient w.r.t. the raw conv output) and the parameter gradients."""
+    """Both backward passes.  Returns dict with draw (gradient w.r.t. the raw conv output) and the parameter gradients."""
     lib = _lib.load()
     n, d, h, w, c = raw.shape
     dims = _dims_cl(raw)
     slots = lib.seunet_epilogue_slots(dims)
     dx = torch.empty_like(raw)
-    stat = torch.zeros((n, slots, c, 2), dtype=torch.float32, device=raw.device)
+    stat = torch.zeros((n, slots, c, 2), dtype=torch.float64, device=raw.device)
     pg = torch.zeros((n * slots, 4 * c + 4), dtype=torch.float32, device=raw.device)
     f = lambda t: None if t is None else t.contiguous().float().reshape(-1)
     ws, ws2, wsd, bsd, hw = f(w_se), f(w_se2), f(w_side), f(b_side), f(head_w)
-    _lib.check(lib.seunet_gate_epilogue_bwd(_code(raw), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), c, _lib.ptr(ws),
-                                            _lib.ptr(ws2), _lib.ptr(wsd), _lib.ptr(bsd), slope, _lib.ptr(g_e),
-                                            _lib.ptr(g_side), _lib.ptr(g_level), _lib.ptr(hw), _lib.ptr(drop), drop_stride,
-                                            dx.data_ptr(), stat.data_ptr(), pg.data_ptr(), dims, _s()), "gate_epilogue_bwd")
-    m1, m2 = stats_finalize(stat, slots, d * h * w, 0.0, 1)
+
+    def call(m1, m2, out, st, pgp):
+        _lib.check(lib.seunet_gate_epilogue_bwd(_code(raw), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), c, _lib.ptr(ws),
+                                                _lib.ptr(ws2), _lib.ptr(wsd), _lib.ptr(bsd), slope, _lib.ptr(g_e),
+                                                _lib.ptr(g_side), _lib.ptr(g_level), _lib.ptr(hw), _lib.ptr(drop), drop_stride,
+                                                _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(out), _lib.ptr(st), _lib.ptr(pgp), dims, _s()),
+                   "gate_epilogue_bwd")
+    call(None, None, None, stat, pg)
+    m1, m2 = stats_finalize_f64(stat, slots, d * h * w)
     dev = raw.device
     out = {"dw_se": torch.empty(c, device=dev), "dw_se2": torch.empty(c, device=dev), "dw_side": torch.empty(2 * c, device=dev),
            "db_side": torch.empty(2, device=dev), "dhead_w": torch.empty(2, device=dev)}
     _lib.check(lib.seunet_pgrad_reduce(pg.data_ptr(), n * slots, c, out["dw_se"].data_ptr(), out["dw_se2"].data_ptr(),
                                        out["dw_side"].data_ptr(), out["db_side"].data_ptr(), out["dhead_w"].data_ptr(), _s()),
                "pgrad_reduce")
-    _lib.check(lib.seunet_in_bwd(_code(raw), dx.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m1.data_ptr(),
-                                 m2.data_ptr(), c, dims, _s()), "in_bwd")
+    call(m1, m2, dx, None, None)
     out["draw"] = dx
     return out
 
@@ -192,18 +204,18 @@ def cat_epilogue_bwd(g_out, raw, mean, rstd, raw2=None, mean2=None, rstd2=None, 
     slots = lib.seunet_epilogue_slots(dims)
     dx = torch.empty_like(raw)
     dx2 = torch.empty_like(raw) if raw2 is not None else None
-    st = torch.zeros((n, slots, c, 2), dtype=torch.float32, device=raw.device)
+    st = torch.zeros((n, slots, c, 2), dtype=torch.float64, device=raw.device)
     st2 = torch.zeros_like(st) if raw2 is not None else None
-    _lib.check(lib.seunet_cat_epilogue_bwd(_code(raw), g_out.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                           _lib.ptr(raw2), _lib.ptr(mean2), _lib.ptr(rstd2), c, slope, dx.data_ptr(),
-                                           _lib.ptr(dx2), st.data_ptr(), _lib.ptr(st2), dims, _s()), "cat_epilogue_bwd")
-    m1, m2 = stats_finalize(st, slots, d * h * w, 0.0, 1)
-    _lib.check(lib.seunet_in_bwd(_code(raw), dx.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m1.data_ptr(),
-                                 m2.data_ptr(), c, dims, _s()), "in_bwd")
-    if raw2 is not None:
-        a1, a2 = stats_finalize(st2, slots, d * h * w, 0.0, 1)
-        _lib.check(lib.seunet_in_bwd(_code(raw), dx2.data_ptr(), raw2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
-                                     a1.data_ptr(), a2.data_ptr(), c, dims, _s()), "in_bwd")
+
+    def call(m1, m2, m1b, m2b, o1, o2, s1, s2):
+        _lib.check(lib.seunet_cat_epilogue_bwd(_code(raw), g_out.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               _lib.ptr(raw2), _lib.ptr(mean2), _lib.ptr(rstd2), c, slope, _lib.ptr(m1), _lib.ptr(m2),
+                                               _lib.ptr(m1b), _lib.ptr(m2b), _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(s1), _lib.ptr(s2),
+                                               dims, _s()), "cat_epilogue_bwd")
+    call(None, None, None, None, None, None, st, st2)
+    m1, m2 = stats_finalize_f64(st, slots, d * h * w)
+    m1b, m2b = stats_finalize_f64(st2, slots, d * h * w) if raw2 is not None else (None, None)
+    call(m1, m2, m1b, m2b, dx, dx2, None, None)
     return dx, dx2
 
 
