@@ -42,14 +42,15 @@ int seunet_unpack_cl(int dtype, const void* in_cl, int c, float* out_ncdhw, seun
  * src/dst lists realise torch.cat (SE_UNet.py:186,195,204,212,216,218,222,224,228) and its backward.
  * weights: SEUNET_CONV_MFMA -> buffer produced by seunet_conv_pack_weights; SEUNET_CONV_NAIVE -> the
  * PyTorch (Cout,Cin,k,k,k) f32 tensor.  transpose_flip=1 selects the data-gradient operator.
- * stats_partial (optional): [n][seunet_conv_stats_slots][cout][2] f32 partial (sum, sum of squares)
- * for the following InstanceNorm3d (SE_UNet.py:17,43,59). */
+ * stats_partial (optional): [n][seunet_conv_stats_slots][cout][2] f64 partial (sum, sum of squares) for the
+ * following InstanceNorm3d (SE_UNet.py:17,43,59).  f64 because var = E[x^2]-E[x]^2 must survive |mean| >> std
+ * (the CPU reference accumulates in double); the network's gradient is ill-conditioned w.r.t. such errors. */
 size_t seunet_conv_wpack_bytes(int dtype, int taps, int cin, int cout);
 int seunet_conv_pack_weights(int dtype, const float* w, int taps, int cin, int cout, int transpose_flip, void* wpack, seunet_stream_t s);
 int seunet_conv_stats_slots(int impl, seunet_dims dims);
 int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
                       int cin, const void* weights, int transpose_flip, const float* bias, int ndst, void* const* dst,
-                      const int* dst_c, const int* dst_accumulate, float* stats_partial, seunet_dims dims, seunet_stream_t s);
+                      const int* dst_c, const int* dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s);
 size_t seunet_conv3d_wgrad_workspace_bytes(int taps, int cin, int cout);
 int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
                         int cin, const void* dy, int cout, float* dw, void* workspace, size_t workspace_bytes,
@@ -57,9 +58,9 @@ int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, c
 
 /* ---- InstanceNorm3d statistics (eps, biased variance; SE_UNet.py:17,43,59) -------------------------- */
 int seunet_epilogue_slots(seunet_dims dims);
-int seunet_channel_stats(int dtype, const void* t, int c, float* partial, seunet_dims dims, seunet_stream_t s);
+int seunet_channel_stats(int dtype, const void* t, int c, double* partial, seunet_dims dims, seunet_stream_t s);
 /* mode 0: (mean, rstd) ; mode 1: (sum/count, sumsq/count) */
-int seunet_stats_finalize(const float* partial, int slots, int c, int n, long long count, float eps, int mode,
+int seunet_stats_finalize(const double* partial, int slots, int c, int n, long long count, float eps, int mode,
                           float* out_a, float* out_b, seunet_stream_t s);
 
 /* ---- gated block epilogue: IN -> LeakyReLU -> gate(s) -> e, side = conv1x1(e); SE_UNet.py:24-35,68-82 --
@@ -74,7 +75,7 @@ int seunet_gate_epilogue_fwd(int dtype, const void* raw, const float* mean, cons
  * result is rounded exactly once):
  *   pass A (m1 == NULL): stat_partial f64 [n][slots][c][2] = sums of dxhat, dxhat*xhat; pgrad_partial f32
  *                        [n*slots][4c+4] = dw_se | dw_se2 | dw_side[2][c] | db_side[2] | dhead_w[2]
- *   seunet_stats_finalize_f64 -> m1, m2 ; seunet_pgrad_reduce -> parameter gradients
+ *   seunet_stats_finalize(mode 1) -> m1, m2 ; seunet_pgrad_reduce -> parameter gradients
  *   pass B (m1, m2 given): draw_out = rstd*(dxhat - m1 - xhat*m2), gradient w.r.t. the raw conv output
  *                          (may alias g_e). */
 int seunet_gate_epilogue_bwd(int dtype, const void* raw, const float* mean, const float* rstd, int c, const float* w_se,
@@ -82,8 +83,6 @@ int seunet_gate_epilogue_bwd(int dtype, const void* raw, const float* mean, cons
                              const float* g_side, const float* g_level, const float* head_w, const float* drop,
                              int drop_stride, const float* m1, const float* m2, void* draw_out, double* stat_partial,
                              float* pgrad_partial, seunet_dims dims, seunet_stream_t s);
-int seunet_stats_finalize_f64(const double* partial, int slots, int c, int n, long long count, float* out_a,
-                              float* out_b, seunet_stream_t s);
 int seunet_pgrad_reduce(const float* pgrad_partial, int records, int c, float* dw_se, float* dw_se2, float* dw_side,
                         float* db_side, float* dhead_w, seunet_stream_t s);
 

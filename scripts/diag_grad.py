@@ -22,11 +22,17 @@ print("fwd max|err| pred0 %.3e pred1 %.3e (|ref| max %.3f)" % (float((ge.cpu() -
 loss = A.fused_stage_loss(1, ge, gd, b["label"].cuda())
 loss.backward()
 print("loss %.7f ref %.7f" % (float(loss), float(l_ref)))
-for (n, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
-    if q.grad is None:
+o64 = orc.build_oracle(2, 1, 1, 0).double()
+pe64, pd64 = o64(b["image"].double())
+orc.stage_loss(1, pe64, pd64, b["label"].double()).backward()
+print("fwd vs fp64 oracle: HIP pred1 %.3e | fp32 oracle pred1 %.3e" % (float((gd.detach().cpu().double() - pd64).abs().max()), float((pd.double() - pd64).abs().max())))
+print("%-22s %-12s %-12s %-12s" % ("param", "HIP-vs-f64", "orc32-vs-f64", "HIP-vs-orc32"))
+for (n, p), (_, q), (_, q64) in zip(m.named_parameters(), o.named_parameters(), o64.named_parameters()):
+    if q.grad is None or n.endswith("conv1.bias"):
         continue
-    r = q.grad.double(); g = p.grad.cpu().double()
-    print("%-22s rel %.3e  norm %.3e" % (n, float((g - r).norm() / max(float(r.norm()), 1e-30)), float(r.norm())))
+    r = q64.grad; g = p.grad.cpu().double(); r32 = q.grad.double()
+    nr = max(float(r.norm()), 1e-30)
+    print("%-22s %.3e    %.3e    %.3e" % (n, float((g - r).norm() / nr), float((r32 - r).norm() / nr), float((g - r32).norm() / nr)))
 # is the HIP backward consistent with the HIP forward?  directional finite difference in fp32
 if dtype == "fp32":
     torch.manual_seed(0)

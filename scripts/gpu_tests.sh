@@ -1,12 +1,11 @@
+# GPU test driver used with gpurun (scripts/ travels with the snapshot, gpurun_out/ does not)
 mkdir -p gpurun_out
-timeout -k 10 700 python -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/ops1.log 2>&1
+timeout -k 10 700 python -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/ops.log 2>&1
 rc=$?
-echo "ops rc=$rc" | tee -a gpurun_out/ops1.log
-tail -5 gpurun_out/ops1.log
+echo "ops rc=$rc"; tail -3 gpurun_out/ops.log
 if [ $rc -le 1 ]; then
-  timeout -k 10 700 python -m pytest tests/test_net_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/net1.log 2>&1
+  timeout -k 10 900 python -m pytest tests/test_net_gpu.py -m gpu -q -s -p no:cacheprovider > gpurun_out/net.log 2>&1
   rc2=$?
-  echo "net rc=$rc2" | tee -a gpurun_out/net1.log
-  tail -5 gpurun_out/net1.log
+  echo "net rc=$rc2"; grep -E "HIP-vs-f64|bf16 logits|passed|failed|FAILED" gpurun_out/net.log | tail -20
 fi
 exit 0

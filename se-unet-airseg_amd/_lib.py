@@ -50,7 +50,6 @@ PROTOTYPES = {
     "seunet_stats_finalize": (_i, [_vp, _i, _i, _i, _ll, _f, _i, _vp, _vp, _vp]),
     "seunet_gate_epilogue_fwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _i, Dims, _vp]),
     "seunet_gate_epilogue_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),
-    "seunet_stats_finalize_f64": (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
     "seunet_pgrad_reduce": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "seunet_cat_epilogue_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, Dims, _vp]),
     "seunet_cat_epilogue_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),

@@ -40,7 +40,7 @@ int seunet_conv_stats_slots(int impl, seunet_dims dims) {
 }
 int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c, int cin,
                       const void* weights, int tflip, const float* bias, int ndst, void* const* dst, const int* dst_c,
-                      const int* dst_acc, float* stats_partial, seunet_dims dims, seunet_stream_t s) {
+                      const int* dst_acc, double* stats_partial, seunet_dims dims, seunet_stream_t s) {
   SrcList sl;
   if (int e = make_src(nsrc, src, src_c, sl)) return e;
   SEUNET_CHECK(ndst >= 1 && ndst <= 3 && dst && dst_c && weights, "conv3d_fwd: bad destination list / weights");
@@ -70,11 +70,11 @@ int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, c
 }
 
 int seunet_epilogue_slots(seunet_dims dims) { return epi_partials(D(dims)); }
-int seunet_channel_stats(int dtype, const void* t, int c, float* partial, seunet_dims dims, seunet_stream_t s) {
+int seunet_channel_stats(int dtype, const void* t, int c, double* partial, seunet_dims dims, seunet_stream_t s) {
   SEUNET_CHECK(t && partial, "channel_stats: null tensor");
   return launch_channel_stats(dtype, t, c, partial, D(dims), S(s));
 }
-int seunet_stats_finalize(const float* partial, int slots, int c, int n, long long count, float eps, int mode, float* out_a,
+int seunet_stats_finalize(const double* partial, int slots, int c, int n, long long count, float eps, int mode, float* out_a,
                           float* out_b, seunet_stream_t s) {
   SEUNET_CHECK(partial && out_a && out_b && slots >= 1 && count >= 1, "stats_finalize: bad argument");
   return launch_stats_finalize(partial, slots, c, n, count, eps, mode, out_a, out_b, S(s));
@@ -101,11 +101,6 @@ int seunet_gate_epilogue_bwd(int dtype, const void* raw, const float* mean, cons
   SseBwdIn g{g_e, g_side, g_level};
   SseHead h{nullptr, nullptr, 0, head_w, drop, drop_stride};
   return launch_sse_bwd(dtype, raw, mean, rstd, c, p, g, h, m1, m2, draw_out, stat_partial, pgrad_partial, D(dims), S(s));
-}
-int seunet_stats_finalize_f64(const double* partial, int slots, int c, int n, long long count, float* out_a, float* out_b,
-                              seunet_stream_t s) {
-  SEUNET_CHECK(partial && out_a && out_b && slots >= 1 && count >= 1, "stats_finalize_f64: bad argument");
-  return launch_stats_finalize_f64(partial, slots, c, n, count, out_a, out_b, S(s));
 }
 int seunet_pgrad_reduce(const float* pgrad_partial, int records, int c, float* dw_se, float* dw_se2, float* dw_side,
                         float* db_side, float* dhead_w, seunet_stream_t s) {

@@ -36,7 +36,7 @@ struct ConvKArgs {
   int dcum1, dcum2;
   int dacc0, dacc1, dacc2;
   int cout;
-  float* stats;
+  double* stats;
   int N, D, H, W;
   int tx, ty, tz;            // tile counts
   int nchunks;
@@ -155,10 +155,10 @@ conv_igemm_kernel(ConvKArgs a) {
 
   // ---- epilogue: bias, store / accumulate, InstanceNorm partial sums ----
   const int gz = z0 + wave;
-  float s1[NSUB], s2[NSUB];
+  double s1[NSUB], s2[NSUB];   // f64: var = E[x^2]-E[x]^2 must survive |mean| >> std
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
-    s1[ns] = 0.f; s2[ns] = 0.f;
+    s1[ns] = 0.0; s2[ns] = 0.0;
     const int co = ntile * NCOL + ns * 32 + col;
     const bool cvalid = co < a.cout;
     void* dpv = a.dst0; int dC = a.dstC0, dacc = a.dacc0, cl = co;
@@ -175,8 +175,8 @@ conv_igemm_kernel(ConvKArgs a) {
         const bool inb = cvalid && gz < a.D && gy < a.H && gx < a.W;
         float val = acc[ms][ns][r] + bias;
         if (inb) {
-          s1[ns] += val;
-          s2[ns] += val * val;
+          s1[ns] += (double)val;
+          s2[ns] += (double)val * (double)val;
           if (dp != nullptr) {
             T* q = dp + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * dC + cl;
             if (dacc) val += to_f32(*q);
@@ -188,11 +188,11 @@ conv_igemm_kernel(ConvKArgs a) {
   }
   if (a.stats != nullptr) {
     __syncthreads();  // all waves are done reading the tiles; reuse LDS
-    float* red = reinterpret_cast<float*>(smem);  // [4][NCOL][2]
+    double* red = reinterpret_cast<double*>(smem);  // [4][NCOL][2]
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
-      const float u = s1[ns] + __shfl_xor(s1[ns], 32, 64);
-      const float v = s2[ns] + __shfl_xor(s2[ns], 32, 64);
+      const double u = s1[ns] + __shfl_xor(s1[ns], 32, 64);
+      const double v = s2[ns] + __shfl_xor(s2[ns], 32, 64);
       if (h == 0) {
         red[(wave * NCOL + ns * 32 + col) * 2] = u;
         red[(wave * NCOL + ns * 32 + col) * 2 + 1] = v;
@@ -203,7 +203,7 @@ conv_igemm_kernel(ConvKArgs a) {
       const int c = tid >> 1, k = tid & 1;
       const int co = ntile * NCOL + c;
       if (co < a.cout) {
-        const float tot = ((red[(0 * NCOL + c) * 2 + k] + red[(1 * NCOL + c) * 2 + k]) +
+        const double tot = ((red[(0 * NCOL + c) * 2 + k] + red[(1 * NCOL + c) * 2 + k]) +
                            red[(2 * NCOL + c) * 2 + k]) + red[(3 * NCOL + c) * 2 + k];
         a.stats[(((long long)n * gridDim.x + blockIdx.x) * a.cout + co) * 2 + k] = tot;
       }
@@ -306,7 +306,7 @@ static int check_lists(const SrcList& src, const DstList& dst) {
 }
 
 int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_logical, const void* wpack,
-                      const float* bias, const DstList& dst, float* stats, Dims d, hipStream_t s) {
+                      const float* bias, const DstList& dst, double* stats, Dims d, hipStream_t s) {
   if (int e = check_lists(src, dst)) return e;
   SEUNET_CHECK(cin_logical >= 1 && cin_logical <= src.total(), "conv: cin=%d exceeds the source channels %d", cin_logical, src.total());
   SEUNET_CHECK(taps == 27 || taps == 1, "conv: taps=%d unsupported", taps);

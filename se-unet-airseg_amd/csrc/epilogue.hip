@@ -30,74 +30,43 @@ int epi_partials(Dims d) {
 // ----------------------------------------------------------------------------------
 template <typename T, int LPV>
 __global__ void __launch_bounds__(EPI_THREADS)
-channel_stats_kernel(const T* __restrict__ t, int C, float* __restrict__ partial, long long V) {
+channel_stats_kernel(const T* __restrict__ t, int C, double* __restrict__ partial, long long V) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
   constexpr int VPB = EPI_THREADS / LPV;
-  float s1[8], s2[8];
+  double s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
   for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
     float x[8];
     load8(t + ((long long)n * V + v) * C + cg * 8, x);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] += x[j]; s2[j] += x[j] * x[j]; }
+    for (int j = 0; j < 8; ++j) { s1[j] += (double)x[j]; s2[j] += (double)x[j] * (double)x[j]; }
   }
-  __shared__ float red[4][16][16];
+  __shared__ double red[4][16][16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    float a = stride_sum<LPV>(s1[j]), b = stride_sum<LPV>(s2[j]);
+    double a = stride_sum_d<LPV>(s1[j]), b = stride_sum_d<LPV>(s2[j]);
     if (lane < LPV) { red[wave][lane][j] = a; red[wave][lane][8 + j] = b; }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < LPV * 16; i += EPI_THREADS) {
     const int g = i / 16, k = i % 16;
-    const float tot = ((red[0][g][k] + red[1][g][k]) + red[2][g][k]) + red[3][g][k];
+    const double tot = ((red[0][g][k] + red[1][g][k]) + red[2][g][k]) + red[3][g][k];
     const int c = g * 8 + (k & 7);
     partial[(((long long)n * P + blockIdx.x) * C + c) * 2 + (k >> 3)] = tot;
   }
 }
 
-// one wave per (n, c): sums the partial slots in a fixed order in f64
+// one wave per (n, c): sums the f64 partial slots in a fixed order.
+//   mode 0: (mean, rstd = 1/sqrt(biased var + eps))      [InstanceNorm3d forward]
+//   mode 1: (sum/count, sumsq/count)                     [the two means of the InstanceNorm backward]
 __global__ void __launch_bounds__(256)
-stats_finalize_kernel(const float* __restrict__ partial, int slots, int C, int N, double inv_count,
+stats_finalize_kernel(const double* __restrict__ partial, int slots, int C, int N, double inv_count,
                       float eps, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + wave;  // (n, c)
-  if (idx >= N * C) return;
-  const int n = idx / C, c = idx % C;
-  double s1 = 0.0, s2 = 0.0;
-  for (int p = lane; p < slots; p += 64) {
-    const float* q = partial + (((long long)n * slots + p) * C + c) * 2;
-    s1 += (double)q[0];
-    s2 += (double)q[1];
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    s1 += __shfl_xor(s1, off, 64);
-    s2 += __shfl_xor(s2, off, 64);
-  }
-  if (lane == 0) {
-    if (mode == 0) {
-      const double mean = s1 * inv_count;
-      double var = s2 * inv_count - mean * mean;  // biased variance (InstanceNorm3d)
-      if (var < 0.0) var = 0.0;
-      out_a[idx] = (float)mean;
-      out_b[idx] = (float)(1.0 / sqrt(var + (double)eps));
-    } else {
-      out_a[idx] = (float)(s1 * inv_count);
-      out_b[idx] = (float)(s2 * inv_count);
-    }
-  }
-}
-
-// backward statistics: f64 partial sums -> (sum/count, sumsq/count) as f32
-__global__ void __launch_bounds__(256)
-stats_finalize_f64_kernel(const double* __restrict__ partial, int slots, int C, int N, double inv_count,
-                          float* __restrict__ out_a, float* __restrict__ out_b) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + wave;
   if (idx >= N * C) return;
   const int n = idx / C, c = idx % C;
   double s1 = 0.0, s2 = 0.0;
@@ -112,8 +81,16 @@ stats_finalize_f64_kernel(const double* __restrict__ partial, int slots, int C, 
     s2 += __shfl_xor(s2, off, 64);
   }
   if (lane == 0) {
-    out_a[idx] = (float)(s1 * inv_count);
-    out_b[idx] = (float)(s2 * inv_count);
+    if (mode == 0) {
+      const double mean = s1 * inv_count;
+      double var = s2 * inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      out_a[idx] = (float)mean;
+      out_b[idx] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      out_a[idx] = (float)(s1 * inv_count);
+      out_b[idx] = (float)(s2 * inv_count);
+    }
   }
 }
 
@@ -507,7 +484,7 @@ static int check_c(int C) {
   return 0;
 }
 
-int launch_channel_stats(int dtype, const void* t, int C, float* partial, Dims d, hipStream_t s) {
+int launch_channel_stats(int dtype, const void* t, int C, double* partial, Dims d, hipStream_t s) {
   if (int e = check_c(C)) return e;
   dim3 grid(epi_partials(d), d.N);
   SEUNET_LPV_SWITCH(C / 8, {
@@ -520,7 +497,7 @@ int launch_channel_stats(int dtype, const void* t, int C, float* partial, Dims d
   return 0;
 }
 
-int launch_stats_finalize(const float* partial, int slots, int C, int N, long long count, float eps,
+int launch_stats_finalize(const double* partial, int slots, int C, int N, long long count, float eps,
                           int mode, float* out_a, float* out_b, hipStream_t s) {
   stats_finalize_kernel<<<cdiv(N * C, 4), 256, 0, s>>>(partial, slots, C, N, 1.0 / (double)count, eps,
                                                       mode, out_a, out_b);
@@ -542,13 +519,6 @@ int launch_sse_fwd(int dtype, const void* raw, const float* mean, const float* r
       else sse_fwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, (float*)e_out, head, d.vox());
     }
   });
-  SEUNET_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_stats_finalize_f64(const double* partial, int slots, int C, int N, long long count, float* out_a,
-                              float* out_b, hipStream_t s) {
-  stats_finalize_f64_kernel<<<cdiv(N * C, 4), 256, 0, s>>>(partial, slots, C, N, 1.0 / (double)count, out_a, out_b);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

@@ -266,17 +266,17 @@ struct Exec {
       mark("conv_fwd:" + nm);
       if (int e = launch_conv_naive(p.d.dtype, taps, dil, src, cin, w, 0, bias, dst, dm, s)) return e;
       mark("stats");
-      if (int e = launch_channel_stats(p.d.dtype, at(raw_off), cout, fat(p.stats), dm, s)) return e;
+      if (int e = launch_channel_stats(p.d.dtype, at(raw_off), cout, dat(p.stats), dm, s)) return e;
       slots = epi_partials(dm);
     } else {
       mark("pack_w");
       if (int e = launch_conv_pack_weights(p.d.dtype, w, taps, cin, cout, 0, at(wp_off), s)) return e;
       mark("conv_fwd:" + nm);
-      if (int e = launch_conv_igemm(p.d.dtype, taps, dil, src, cin, at(wp_off), bias, dst, fat(p.stats), dm, s)) return e;
+      if (int e = launch_conv_igemm(p.d.dtype, taps, dil, src, cin, at(wp_off), bias, dst, dat(p.stats), dm, s)) return e;
       slots = conv_stats_tiles(dm);
     }
     mark("stats");
-    return launch_stats_finalize(fat(p.stats), slots, cout, dm.N, dm.vox(), p.d.eps, 0, fat(mean_off), fat(rstd_off), s);
+    return launch_stats_finalize(dat(p.stats), slots, cout, dm.N, dm.vox(), p.d.eps, 0, fat(mean_off), fat(rstd_off), s);
   }
 
   SseParams sse_params(const OpDesc& o) const {
@@ -429,7 +429,7 @@ struct Exec {
         if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd, nullptr, nullptr,
                                    nullptr, dat(p.stats), fat(p.pgrad), dm, s)) return e;
         mark("stats");
-        if (int e = launch_stats_finalize_f64(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1), fat(p.m2), s)) return e;
+        if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
         float* g_head = grads[find_param(reg, o.head == 0 ? "dc0_0.weight" : "dc0_1.weight")];
         const int i_se2 = o.gates == 2 ? find_param(reg, n + ".conv_se2.weight") : -1;
         if (int e = launch_pgrad_reduce(fat(p.pgrad), dm.N * P_slots, r.cout, grads[find_param(reg, n + ".conv_se.weight")],
@@ -452,9 +452,9 @@ struct Exec {
                                    p.d.negative_slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dat(p.stats),
                                    dat(p.stats2), dm, s)) return e;
         mark("stats");
-        if (int e = launch_stats_finalize_f64(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1), fat(p.m2), s)) return e;
+        if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
         if (o.xname)
-          if (int e = launch_stats_finalize_f64(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1b), fat(p.m2b), s)) return e;
+          if (int e = launch_stats_finalize(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
         mark("in_bwd:" + n);    // pass B
         if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
                                    p.d.negative_slope, fat(p.m1), fat(p.m2), o.xname ? fat(p.m1b) : nullptr,

@@ -140,7 +140,7 @@ int launch_conv_pack_weights(int dtype, const float* w_torch, int taps, int cin_
 int conv_stats_tiles(Dims d);     // partial-stat slots per sample written by the igemm kernel
 int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_logical,
                       const void* wpack, const float* bias, const DstList& dst,
-                      float* stats_partial, Dims d, hipStream_t s);
+                      double* stats_partial, Dims d, hipStream_t s);
 int launch_conv_naive(int dtype, int taps, int dil, const SrcList& src, int cin_logical,
                       const float* w_torch, int transpose_flip, const float* bias,
                       const DstList& dst, Dims d, hipStream_t s);
@@ -155,8 +155,8 @@ int launch_wgrad_naive(int dtype, int taps, int dil, const SrcList& x, int cin_l
 
 // normalisation / gates / cat (epilogue.hip)
 int epi_partials(Dims d);         // partial slots per sample used by the epilogue kernels
-int launch_channel_stats(int dtype, const void* t, int C, float* partial, Dims d, hipStream_t s);
-int launch_stats_finalize(const float* partial, int slots, int C, int N, long long count,
+int launch_channel_stats(int dtype, const void* t, int C, double* partial, Dims d, hipStream_t s);
+int launch_stats_finalize(const double* partial, int slots, int C, int N, long long count,
                           float eps, int mode, float* out_a, float* out_b, hipStream_t s);
 struct SseParams {
   const float* w_se;      // [C]
@@ -187,8 +187,6 @@ int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* r
                    const SseParams& p, const SseBwdIn& g, const SseHead& head, const float* m1,
                    const float* m2, void* draw_out, double* stat_partial, float* pgrad_partial,
                    Dims d, hipStream_t s);
-int launch_stats_finalize_f64(const double* partial, int slots, int C, int N, long long count,
-                              float* out_a, float* out_b, hipStream_t s);
 int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* dw_se,
                         float* dw_se2, float* dw_side, float* db_side, float* dhead_w,
                         hipStream_t s);

@@ -90,7 +90,7 @@ def conv3d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[to
     stats, slots = None, 0
     if want_stats:
         slots = lib.seunet_conv_stats_slots(impl, dims)
-        stats = torch.zeros((dims.n, slots, sum(dst_channels), 2), dtype=torch.float32, device=srcs[0].device)
+        stats = torch.zeros((dims.n, slots, sum(dst_channels), 2), dtype=torch.float64, device=srcs[0].device)
     b = None if bias is None else bias.contiguous().float()
     _lib.check(lib.seunet_conv3d_fwd(code, impl, taps, dilation, len(srcs), _lib.ptr_array(list(srcs)),
                                      _lib.int_array([t.shape[4] for t in srcs]), cin, wbuf.data_ptr(), int(transpose_flip),
@@ -118,7 +118,7 @@ def channel_stats(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
     lib = _lib.load()
     dims = _dims_cl(t)
     slots = lib.seunet_epilogue_slots(dims)
-    part = torch.zeros((dims.n, slots, t.shape[4], 2), dtype=torch.float32, device=t.device)
+    part = torch.zeros((dims.n, slots, t.shape[4], 2), dtype=torch.float64, device=t.device)
     _lib.check(lib.seunet_channel_stats(_code(t), t.data_ptr(), t.shape[4], part.data_ptr(), dims, _s()), "channel_stats")
     return part, slots
 
@@ -148,15 +148,6 @@ def gate_epilogue_fwd(raw, mean, rstd, w_se, w_se2, w_side, b_side, slope=0.01, 
     return e, side
 
 
-def stats_finalize_f64(partial: torch.Tensor, slots: int, count: int):
-    n, _, c, _ = partial.shape
-    a = torch.empty((n, c), dtype=torch.float32, device=partial.device)
-    b = torch.empty_like(a)
-    _lib.check(_lib.load().seunet_stats_finalize_f64(partial.data_ptr(), slots, c, n, count, a.data_ptr(), b.data_ptr(), _s()),
-               "stats_finalize_f64")
-    return a, b
-
-
 def gate_epilogue_bwd(raw, mean, rstd, w_se, w_se2, w_side, b_side, slope=0.01, g_e=None, g_side=None, g_level=None,
                       head_w=None, drop=None, drop_stride=0):
     """Both backward passes.  Returns dict with draw (gradient w.r.t. the raw conv output) and the parameter gradients."""
@@ -177,7 +168,7 @@ def gate_epilogue_bwd(raw, mean, rstd, w_se, w_se2, w_side, b_side, slope=0.01, 
                                                 _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(out), _lib.ptr(st), _lib.ptr(pgp), dims, _s()),
                    "gate_epilogue_bwd")
     call(None, None, None, stat, pg)
-    m1, m2 = stats_finalize_f64(stat, slots, d * h * w)
+    m1, m2 = stats_finalize(stat, slots, d * h * w, 0.0, 1)
     dev = raw.device
     out = {"dw_se": torch.empty(c, device=dev), "dw_se2": torch.empty(c, device=dev), "dw_side": torch.empty(2 * c, device=dev),
            "db_side": torch.empty(2, device=dev), "dhead_w": torch.empty(2, device=dev)}
@@ -213,8 +204,8 @@ def cat_epilogue_bwd(g_out, raw, mean, rstd, raw2=None, mean2=None, rstd2=None, 
                                                _lib.ptr(m1b), _lib.ptr(m2b), _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(s1), _lib.ptr(s2),
                                                dims, _s()), "cat_epilogue_bwd")
     call(None, None, None, None, None, None, st, st2)
-    m1, m2 = stats_finalize_f64(st, slots, d * h * w)
-    m1b, m2b = stats_finalize_f64(st2, slots, d * h * w) if raw2 is not None else (None, None)
+    m1, m2 = stats_finalize(st, slots, d * h * w, 0.0, 1)
+    m1b, m2b = stats_finalize(st2, slots, d * h * w, 0.0, 1) if raw2 is not None else (None, None)
     call(m1, m2, m1b, m2b, dx, dx2, None, None)
     return dx, dx2
 

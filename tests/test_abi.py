@@ -18,7 +18,7 @@ def declared_symbols():
 def test_header_declares_the_survey_entry_points():
     syms = declared_symbols()
     for must in ("seunet_version", "seunet_last_error", "seunet_conv3d_fwd", "seunet_conv3d_wgrad",
-                 "seunet_gate_epilogue_fwd", "seunet_gate_epilogue_bwd", "seunet_stats_finalize_f64", "seunet_maxpool_fwd",
+                 "seunet_gate_epilogue_fwd", "seunet_gate_epilogue_bwd", "seunet_stats_finalize", "seunet_maxpool_fwd",
                  "seunet_maxpool_bwd", "seunet_head_fwd", "seunet_head_bwd", "seunet_loss_sums", "seunet_loss_grad",
                  "seunet_net_workspace_bytes", "seunet_net_forward", "seunet_net_backward"):
         assert must in syms, must
