@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--cpu-size", type=int, default=128)
+    ap.add_argument("--dump-kernels", default="", help="write the full per-launch-group timing table (TSV) here")
     args = ap.parse_args()
 
     import seunet_amd as A
@@ -162,6 +163,13 @@ def main():
             tag, ms, cnt = line.split("\t")
             rows.append((tag, float(ms), int(cnt)))
         lib_ms = sum(ms for tag, ms, _ in rows if tag != "outside")
+        if args.dump_kernels:
+            with open(args.dump_kernels, "w") as f:
+                f.write("kernel\ttotal_ms\tlaunches\tavg_ms\tTFLOP/s\tGB/s\n")
+                for tag, ms, cnt in sorted(rows, key=lambda r: -r[1]):
+                    fl, by = algorithmic_work(tag, table, esz)
+                    avg = ms / cnt
+                    f.write(f"{tag}\t{ms:.3f}\t{cnt}\t{avg:.4f}\t{fl / (avg * 1e-3) / 1e12:.1f}\t{by / (avg * 1e-3) / 1e9:.1f}\n")
         rows.sort(key=lambda r: -r[1])
         kernels = []
         for tag, ms, cnt in rows[:8]:
@@ -187,7 +195,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import seunet_oracle as orc
-        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = int(os.environ.get("SEUNET_CPU_THREADS", min(cores, 16)))   # a 1-GPU box owns a 16-core share of the host
         torch.set_num_threads(cores)
         o = orc.build_oracle(args.in_channel, 1, 1, seed=0)
         cs = args.cpu_size

@@ -153,7 +153,7 @@ int seunet_net_backward(const seunet_net_desc* desc, const float* const* params,
                         void* workspace, size_t workspace_bytes, seunet_stream_t s);
 
 /* ---- opt-in timing of the launch groups inside seunet_net_forward/backward (HIP events on the caller's
- * stream, thread local).  seunet_prof_report writes "tag<TAB>ms<TAB>count" lines and resets; it waits on
+ * stream; process-wide, meant for one benchmarking thread at a time).  seunet_prof_report writes "tag<TAB>ms<TAB>count" lines and resets; it waits on
  * the recorded events, so call it outside any timed region. */
 int seunet_prof_enable(int on);
 int seunet_prof_report(char* buf, size_t cap);

@@ -28,7 +28,9 @@ struct Prof {
   size_t used = 0;
   std::vector<std::pair<std::string, size_t>> marks;
 };
-static thread_local Prof g_prof;
+// process-wide on purpose: autograd runs the backward call on another thread than the forward call.
+// Only the benchmark enables it, from one thread, around stream-ordered calls.
+static Prof g_prof;
 
 bool prof_on() { return g_prof.on; }
 
@@ -40,7 +42,7 @@ void prof_mark(const char* tag, hipStream_t s) {
     if (hipEventCreate(&e) != hipSuccess) return;
     p.pool.push_back(e);
   }
-  hipEventRecord(p.pool[p.used], s);
+  (void)hipEventRecord(p.pool[p.used], s);
   p.marks.emplace_back(tag, p.used);
   ++p.used;
 }

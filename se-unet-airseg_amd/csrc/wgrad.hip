@@ -6,8 +6,11 @@
 //   workgroup   256 threads = 4 waves, persistent over spatial tiles; LDS holds the X halo tile and the
 //               dY tile as [voxel][32 channels]; the 27 taps are split over the 4 waves (7/7/7/6), each wave
 //               keeping one 32x32 f32 accumulator per tap in registers across ALL its tiles
-//   MFMA        v_mfma_f32_32x32x2_f32 (K-step = 2 voxels; operands are one element per lane, so the
-//               [voxel][channel] LDS image is read with plain conflict-free loads, bf16 widened on read)
+//   MFMA        bf16: v_mfma_f32_32x32x16_bf16, K-step = 16 consecutive x-voxels.  Both operands need "8 voxels of
+//               one channel" per lane while the data is [voxel][channel]: gfx950's transposing LDS read
+//               ds_read_b64_tr_b16 delivers exactly that from the unmodified image (a 16-lane group reads a
+//               4-voxel x 16-channel block, 64-B rows -> conflict-free), tap shifts only move the row address.
+//               f32 : v_mfma_f32_32x32x2_f32 (K-step = 2 voxels, one element per lane, plain loads)
 //   output      each workgroup stores its accumulators once to a slab; a second kernel sums the slabs in a
 //               fixed order (deterministic, no atomics) straight into the PyTorch (Cout,Cin,3,3,3) layout
 #include "seunet_common.h"
@@ -15,6 +18,8 @@
 namespace seunet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 
 struct WgArgs {
   const void* src0; const void* src1; const void* src2;
@@ -29,7 +34,7 @@ struct WgArgs {
 };
 
 template <typename T, int DIL, int TAPS> struct WgTile;
-template <int TAPS> struct WgTile<bf16_t, 1, TAPS> { static constexpr int TZ = 4, TY = 4; };
+template <int TAPS> struct WgTile<bf16_t, 1, TAPS> { static constexpr int TZ = 2, TY = 4; };
 template <int TAPS> struct WgTile<bf16_t, 2, TAPS> { static constexpr int TZ = 2, TY = 4; };
 template <int TAPS> struct WgTile<float, 1, TAPS> { static constexpr int TZ = 2, TY = 4; };
 template <int TAPS> struct WgTile<float, 2, TAPS> { static constexpr int TZ = 1, TY = 2; };
@@ -115,14 +120,37 @@ wgrad_kernel(WgArgs a) {
       const int lz = row / TY, ly = row % TY;
       const int xrow = ((lz * HY + ly) * HX) * 32;      // tap (0,0,0) row start in the halo tile
       const int yrow = (row * TX) * 32;
-#pragma unroll 4
-      for (int kk = 0; kk < 16; ++kk) {
-        const int xo = 2 * kk + h;
-        const float bfr = to_f32(ys[yrow + xo * 32 + col]);
+      if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+        // lane -> (voxel, channel) piece of a 16-voxel x 32-channel operand: 16-lane group grp covers channels
+        // 16*(grp&1).. and voxels 8*(grp>>1)..+3 (second read: +4); lane li supplies row li>>2, columns 4*(li&3)..
+        const int grp = lane >> 4, li = lane & 15;
+        const int lane_off = (8 * (grp >> 1) + (li >> 2)) * 32 + 16 * (grp & 1) + 4 * (li & 3);
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
-          const float afr = to_f32(xs[xrow + (tapoff[ti] + xo) * 32 + col]);
-          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr, bfr, acc[ti], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16_t* yb = reinterpret_cast<const bf16_t*>(ys) + yrow + kk * 16 * 32 + lane_off;
+          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)yb);
+          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(yb + 4 * 32));
+          const bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti) {
+            const bf16_t* xa = reinterpret_cast<const bf16_t*>(xs) + xrow + (tapoff[ti] + kk * 16) * 32 + lane_off;
+            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)xa);
+            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(xa + 4 * 32));
+            const bf16x8 afr = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+          const int xo = 2 * kk + h;
+          const float bfr = to_f32(ys[yrow + xo * 32 + col]);
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti) {
+            const float afr = to_f32(xs[xrow + (tapoff[ti] + xo) * 32 + col]);
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr, bfr, acc[ti], 0, 0, 0);
+          }
         }
       }
     }
@@ -151,20 +179,27 @@ wgrad_kernel(WgArgs a) {
   }
 }
 
-// dW (PyTorch layout) = fixed-order sum of the slabs
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int taps, int cin_w, int cout_w,
-                                    int co_tiles, float* __restrict__ dw, long long total) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % taps);
-    const int ci = (int)((i / taps) % cin_w);
-    const int co = (int)(i / ((long long)taps * cin_w));
-    const int combo = (ci / 32) * co_tiles + co / 32;
-    const float* p = slab + (size_t)combo * nslab * (taps * 1024) + ((size_t)tap * 32 + (ci & 31)) * 32 + (co & 31);
-    double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += (double)p[(size_t)k * (taps * 1024)];
-    dw[i] = (float)s;
+// dW (PyTorch layout) = fixed-order sum of the slabs.  One thread per slab element (tap, ci, co) so that the
+// nslab reads of a wave are contiguous 256-B rows; the (small) scattered write goes to the PyTorch layout.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int taps, int cin_w, int cout_w, int co_tiles,
+                    float* __restrict__ dw) {
+  const int per = taps * 1024;
+  const int e = blockIdx.x * 256 + threadIdx.x;   // element inside one slab
+  const int combo = blockIdx.y;
+  if (e >= per) return;
+  const int tap = e >> 10, ci = (combo / co_tiles) * 32 + ((e >> 5) & 31), co = (combo % co_tiles) * 32 + (e & 31);
+  const float* p = slab + (size_t)combo * nslab * per + e;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= nslab; k += 4) {
+    s0 += (double)p[(size_t)k * per];
+    s1 += (double)p[(size_t)(k + 1) * per];
+    s2 += (double)p[(size_t)(k + 2) * per];
+    s3 += (double)p[(size_t)(k + 3) * per];
   }
+  for (; k < nslab; ++k) s0 += (double)p[(size_t)k * per];
+  if (ci < cin_w && co < cout_w) dw[((size_t)co * cin_w + ci) * taps + tap] = (float)((s0 + s1) + (s2 + s3));
 }
 
 static inline int wgrad_groups(int taps, int combos, int total_tiles) {
@@ -242,10 +277,9 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
     else e = wgrad_launch_one<float, 27, 2>(a, grid, s);
   }
   if (e) return e;
-  const long long total = (long long)cout * cin_logical * taps;
   const int nslab = taps == 27 ? G : 4 * G;
-  wgrad_reduce_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
-      a.slab, nslab, taps, cin_logical, cout, a.co_tiles, dw, total);
+  wgrad_reduce_kernel<<<dim3(cdiv(taps * 1024, 256), combos), 256, 0, s>>>(a.slab, nslab, taps, cin_logical, cout,
+                                                                            a.co_tiles, dw);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
