@@ -47,7 +47,7 @@ int seunet_unpack_cl(int dtype, const void* in_cl, int c, float* out_ncdhw, seun
  * (the CPU reference accumulates in double); the network's gradient is ill-conditioned w.r.t. such errors. */
 size_t seunet_conv_wpack_bytes(int dtype, int taps, int cin, int cout);
 int seunet_conv_pack_weights(int dtype, const float* w, int taps, int cin, int cout, int transpose_flip, void* wpack, seunet_stream_t s);
-int seunet_conv_stats_slots(int impl, seunet_dims dims);
+int seunet_conv_stats_slots(int impl, int taps, int dilation, seunet_dims dims);
 int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
                       int cin, const void* weights, int transpose_flip, const float* bias, int ndst, void* const* dst,
                       const int* dst_c, const int* dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s);

@@ -41,7 +41,7 @@ PROTOTYPES = {
     "seunet_unpack_cl": (_i, [_i, _vp, _i, _vp, Dims, _vp]),
     "seunet_conv_wpack_bytes": (_sz, [_i, _i, _i, _i]),
     "seunet_conv_pack_weights": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "seunet_conv_stats_slots": (_i, [_i, Dims]),
+    "seunet_conv_stats_slots": (_i, [_i, _i, _i, Dims]),
     "seunet_conv3d_fwd": (_i, [_i, _i, _i, _i, _i, _pp, _ip, _i, _vp, _i, _vp, _i, _pp, _ip, _ip, _vp, Dims, _vp]),
     "seunet_conv3d_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "seunet_conv3d_wgrad": (_i, [_i, _i, _i, _i, _i, _pp, _ip, _i, _vp, _i, _vp, _vp, _sz, Dims, _vp]),

@@ -35,8 +35,8 @@ int seunet_conv_pack_weights(int dtype, const float* w, int taps, int cin, int c
   SEUNET_CHECK(w && wpack, "conv_pack_weights: null tensor");
   return launch_conv_pack_weights(dtype, w, taps, cin, cout, tflip, wpack, S(s));
 }
-int seunet_conv_stats_slots(int impl, seunet_dims dims) {
-  return impl == SEUNET_CONV_NAIVE ? epi_partials(D(dims)) : conv_stats_tiles(D(dims));
+int seunet_conv_stats_slots(int impl, int taps, int dilation, seunet_dims dims) {
+  return impl == SEUNET_CONV_NAIVE ? epi_partials(D(dims)) : conv_stats_tiles(D(dims), taps, dilation);
 }
 int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c, int cin,
                       const void* weights, int tflip, const float* bias, int ndst, void* const* dst, const int* dst_c,

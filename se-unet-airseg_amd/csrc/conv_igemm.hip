@@ -6,15 +6,23 @@
 //   GEMM view     M = voxels, N = output channels, K = taps x input channels
 //   workgroup     256 threads = 4 waves; output tile 4(z) x 4(y) x 32(x) voxels; wave w owns z-slice w,
 //                 i.e. four 32-voxel x-rows, times all N columns of the tile (32 or 64)
+//   dilation 2    decomposes into 8 independent dilation-1 problems on the parity sub-lattices
+//                 (voxel = 2*lattice + parity): the tile lives on one sub-lattice, so the halo is 1 lattice
+//                 voxel (39 KB tile) instead of 2 voxels (74 KB), and the rest of the kernel is unchanged
 //   MFMA          bf16: v_mfma_f32_32x32x16_bf16 (K-step = 16 channels of one tap)
 //                 f32 : v_mfma_f32_32x32x2_f32   (exact f32 FMA chain; the 1e-3 parity mode)
-//   LDS           input halo tile [(4+2d)(4+2d)(32+2d) voxels][32 B = one K-chunk], 16-B slots XOR-swizzled
-//                 by voxel bit 3 so a ds_read_b128 of 16 consecutive voxels is conflict-free;
-//                 weight slab [tap][k-half][column][8 x bf16] (one contiguous 16-B fragment per lane)
-//   K loop        chunks of 32 bytes of channels (16 bf16 / 8 f32): fill tile + weights, barrier, 27 taps of MFMAs
-//   epilogue      + bias, store (optionally += for gradient accumulation, optionally split over up to three
-//                 destination tensors = backward of the fused concatenation), per-(n,c) InstanceNorm partial
-//                 sums taken from the f32 accumulators (wave shuffle + fixed-order cross-wave sum)
+//   LDS           input halo tile [6*6*34 voxels][32 B = one K-chunk], 16-B slots XOR-swizzled by voxel bit 3
+//                 so a ds_read_b128 of 16 consecutive voxels is conflict-free; weight slab
+//                 [tap][k-half][column][8 x bf16] (one contiguous 16-B fragment per lane)
+//   K loop        chunks of 32 bytes of channels (16 bf16 / 8 f32).  The NEXT chunk's tile and weights are
+//                 fetched into registers (fully unrolled 16-B loads, all in flight) while the current
+//                 chunk's 27 taps of MFMAs run; they are written to LDS after the barrier (split
+//                 issue-early / write-late staging)
+//   epilogue      + bias; per-(n,c) InstanceNorm partial sums in f64 from the f32 accumulators (wave shuffle +
+//                 fixed-order cross-wave sum); the tile is transposed through LDS so that every lane stores
+//                 16 B (8 channels of one voxel), optionally += (gradient accumulation) and split over up to
+//                 three destination tensors (backward of the fused concatenation)
+//   grid          blockIdx.x is remapped so that each XCD (private L2) owns a contiguous run of tiles
 #include "seunet_common.h"
 
 namespace seunet {
@@ -38,7 +46,7 @@ struct ConvKArgs {
   int cout;
   double* stats;
   int N, D, H, W;
-  int tx, ty, tz;            // tile counts
+  int tx, ty, tz;            // tile counts (on the sub-lattice when dilated)
   int nchunks;
 };
 
@@ -46,28 +54,94 @@ template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { static constexpr int KC = 16, KSTEPS = 1; };
 template <> struct Frag<float> { static constexpr int KC = 8, KSTEPS = 4; };
 
+__device__ __forceinline__ void store_vec8(float* q, const float (&v)[8], int acc) {
+  if (acc) { float o[8]; load8(q, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] += v[j];
+    store8(q, o);
+  } else store8(q, v);
+}
+__device__ __forceinline__ void store_vec8(bf16_t* q, const float (&v)[8], int acc) {
+  if (acc) { float o[8]; load8(q, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] += v[j];
+    store8(q, o);
+  } else store8(q, v);
+}
+
 template <typename T, int NSUB, int TAPS, int DIL>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(ConvKArgs a) {
   constexpr int KC = Frag<T>::KC, KSTEPS = Frag<T>::KSTEPS;
-  constexpr int HALO = (TAPS == 27) ? DIL : 0;
+  constexpr int HALO = (TAPS == 27) ? 1 : 0;
+  constexpr int STEP = (TAPS == 27) ? DIL : 1;              // voxel stride of the (sub-)lattice
   constexpr int HZ = CV_TZ + 2 * HALO, HY = CV_TY + 2 * HALO, HX = CV_TX + 2 * HALO;
   constexpr int NVH = HZ * HY * HX;
   constexpr int NCOL = 32 * NSUB;
   constexpr int T3 = (TAPS == 27) ? 3 : 1;
+  constexpr int IN_ITEMS = (NVH * 2 + 255) / 256;
+  constexpr int W_TOTAL = TAPS * NCOL * 2;                  // 16-byte pieces of one weight slab
+  constexpr int W_ITEMS = (W_TOTAL + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* in_tile = smem;
   unsigned char* w_tile = smem + NVH * 32;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
-  int t = blockIdx.x;
+  // XCD-aware order: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous run of tiles
+  int t;
+  {
+    const int nt = gridDim.x, b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_slot = t;
   const int bx = t % a.tx; t /= a.tx;
-  const int by = t % a.ty;
-  const int bz = t / a.ty;
-  const int x0 = bx * CV_TX, y0 = by * CV_TY, z0 = bz * CV_TZ;
+  const int by = t % a.ty; t /= a.ty;
+  const int bz = t % a.tz;
+  const int par = t / a.tz;                                  // parity class 0..STEP^3-1
+  const int px = par % STEP, py = (par / STEP) % STEP, pz = par / (STEP * STEP);
+  const int x0 = bx * CV_TX, y0 = by * CV_TY, z0 = bz * CV_TZ;   // lattice coordinates
   const int ntile = blockIdx.y, n = blockIdx.z;
   const long long V = (long long)a.D * a.H * a.W;
+
+  // ---- per-thread staging plan: which halo voxels this thread fetches (chunk independent) ----
+  const int piece = tid & 1;
+  int voff[IN_ITEMS];
+#pragma unroll
+  for (int k = 0; k < IN_ITEMS; ++k) {
+    const int idx = tid + 256 * k;
+    const int vox = idx >> 1;
+    const int hx = vox % HX;
+    const int r2 = vox / HX;
+    const int hy = r2 % HY, hz = r2 / HY;
+    const int gz = STEP * (z0 - HALO + hz) + pz, gy = STEP * (y0 - HALO + hy) + py, gx = STEP * (x0 - HALO + hx) + px;
+    const bool ok = idx < NVH * 2 && (z0 - HALO + hz) >= 0 && (y0 - HALO + hy) >= 0 && (x0 - HALO + hx) >= 0 &&
+                    gz < a.D && gy < a.H && gx < a.W;
+    voff[k] = ok ? (gz * a.H + gy) * a.W + gx : -1;
+  }
+  const uint4* wbase = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.wpack) +
+                                                      (size_t)ntile * a.nchunks * (size_t)(W_TOTAL * 16));
+  uint4 rin[IN_ITEMS], rw[W_ITEMS];
+  auto prefetch = [&](int chunk) {
+    const int ch0 = chunk * KC + piece * (KC / 2);
+    const void* sp = a.src0; int sC = a.srcC0, c = ch0;
+    if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
+    else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
+    const T* base = reinterpret_cast<const T*>(sp) + (long long)n * V * sC + c;
+    const bool chv = ch0 < a.cin;
+#pragma unroll
+    for (int k = 0; k < IN_ITEMS; ++k) {
+      rin[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (chv && voff[k] >= 0) rin[k] = *reinterpret_cast<const uint4*>(base + (long long)voff[k] * sC);
+    }
+    const uint4* wsrc = wbase + (size_t)chunk * W_TOTAL;
+#pragma unroll
+    for (int k = 0; k < W_ITEMS; ++k) {
+      const int idx = tid + 256 * k;
+      rw[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (idx < W_TOTAL) rw[k] = wsrc[idx];
+    }
+  };
 
   f32x16 acc[4][NSUB];
 #pragma unroll
@@ -77,36 +151,22 @@ conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
+  prefetch(0);
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    __syncthreads();
-    // ---- stage the input halo tile for this K-chunk (zero padding outside the volume) ----
-    for (int idx = tid; idx < NVH * 2; idx += 256) {
-      const int vox = idx >> 1, piece = idx & 1;
-      const int hx = vox % HX;
-      const int r2 = vox / HX;
-      const int hy = r2 % HY, hz = r2 / HY;
-      const int gz = z0 - HALO + hz, gy = y0 - HALO + hy, gx = x0 - HALO + hx;
-      uint4 val = make_uint4(0u, 0u, 0u, 0u);
-      const int ch0 = chunk * KC + piece * (KC / 2);
-      if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
-          ch0 < a.cin) {
-        const void* sp = a.src0; int sC = a.srcC0, c = ch0;
-        if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
-        else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
-        const T* p = reinterpret_cast<const T*>(sp) +
-                     ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * sC + c;
-        val = *reinterpret_cast<const uint4*>(p);
-      }
-      *reinterpret_cast<uint4*>(in_tile + vox * 32 + 16 * (piece ^ ((vox >> 3) & 1))) = val;
+    __syncthreads();   // every wave is done reading the previous chunk's tiles
+#pragma unroll
+    for (int k = 0; k < IN_ITEMS; ++k) {
+      const int idx = tid + 256 * k;
+      const int vox = idx >> 1;
+      if (idx < NVH * 2) *reinterpret_cast<uint4*>(in_tile + vox * 32 + 16 * (piece ^ ((vox >> 3) & 1))) = rin[k];
     }
-    // ---- stage this chunk's weight slab (pre-packed as the exact LDS image) ----
-    {
-      const uint4* wsrc = reinterpret_cast<const uint4*>(
-          reinterpret_cast<const unsigned char*>(a.wpack) +
-          (size_t)(ntile * a.nchunks + chunk) * (size_t)(TAPS * NCOL * 32));
-      for (int idx = tid; idx < TAPS * NCOL * 2; idx += 256) reinterpret_cast<uint4*>(w_tile)[idx] = wsrc[idx];
+#pragma unroll
+    for (int k = 0; k < W_ITEMS; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < W_TOTAL) reinterpret_cast<uint4*>(w_tile)[idx] = rw[k];
     }
     __syncthreads();
+    if (chunk + 1 < a.nchunks) prefetch(chunk + 1);   // in flight while the MFMAs below run
 
     // ---- MFMA over taps ----
     for (int tz3 = 0; tz3 < T3; ++tz3) {
@@ -153,41 +213,33 @@ conv_igemm_kernel(ConvKArgs a) {
     }
   }
 
-  // ---- epilogue: bias, store / accumulate, InstanceNorm partial sums ----
-  const int gz = z0 + wave;
-  double s1[NSUB], s2[NSUB];   // f64: var = E[x^2]-E[x]^2 must survive |mean| >> std
+  // ---- epilogue ----
+  // (1) bias + f64 InstanceNorm partial sums from the accumulators
+  const int gz_w = STEP * (z0 + wave) + pz;
+  double s1[NSUB], s2[NSUB];
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
     s1[ns] = 0.0; s2[ns] = 0.0;
     const int co = ntile * NCOL + ns * 32 + col;
     const bool cvalid = co < a.cout;
-    void* dpv = a.dst0; int dC = a.dstC0, dacc = a.dacc0, cl = co;
-    if (co >= a.dcum2) { dpv = a.dst2; dC = a.dstC2; dacc = a.dacc2; cl = co - a.dcum2; }
-    else if (co >= a.dcum1) { dpv = a.dst1; dC = a.dstC1; dacc = a.dacc1; cl = co - a.dcum1; }
-    T* dp = reinterpret_cast<T*>(dpv);
     const float bias = (a.bias != nullptr && cvalid) ? a.bias[co] : 0.f;
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
-      const int gy = y0 + ms;
+      const int gy = STEP * (y0 + ms) + py;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool inb = cvalid && gz < a.D && gy < a.H && gx < a.W;
-        float val = acc[ms][ns][r] + bias;
-        if (inb) {
+        const int gx = STEP * (x0 + (r & 3) + 8 * (r >> 2) + 4 * h) + px;
+        const float val = acc[ms][ns][r] + bias;
+        acc[ms][ns][r] = val;
+        if (a.stats != nullptr && cvalid && gz_w < a.D && gy < a.H && gx < a.W) {
           s1[ns] += (double)val;
           s2[ns] += (double)val * (double)val;
-          if (dp != nullptr) {
-            T* q = dp + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * dC + cl;
-            if (dacc) val += to_f32(*q);
-            *q = from_f32<T>(val);
-          }
         }
       }
     }
   }
+  __syncthreads();   // all waves are done with the K-loop tiles; LDS is reused below
   if (a.stats != nullptr) {
-    __syncthreads();  // all waves are done reading the tiles; reuse LDS
     double* red = reinterpret_cast<double*>(smem);  // [4][NCOL][2]
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
@@ -204,10 +256,49 @@ conv_igemm_kernel(ConvKArgs a) {
       const int co = ntile * NCOL + c;
       if (co < a.cout) {
         const double tot = ((red[(0 * NCOL + c) * 2 + k] + red[(1 * NCOL + c) * 2 + k]) +
-                           red[(2 * NCOL + c) * 2 + k]) + red[(3 * NCOL + c) * 2 + k];
-        a.stats[(((long long)n * gridDim.x + blockIdx.x) * a.cout + co) * 2 + k] = tot;
+                            red[(2 * NCOL + c) * 2 + k]) + red[(3 * NCOL + c) * 2 + k];
+        a.stats[(((long long)n * gridDim.x + tile_slot) * a.cout + co) * 2 + k] = tot;
       }
     }
+    __syncthreads();
+  }
+  // (2) transpose through LDS in two halves (z-slices {0,1}, {2,3}) and store 8 channels (16/32 B) per lane
+  float* stage = reinterpret_cast<float*>(smem);   // [256 voxels][NCOL] f32
+  constexpr int GRP = NCOL / 8;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((wave >> 1) == half) {
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int xl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            stage[((((wave & 1) * 4 + ms) * 32 + xl) * NCOL) + ns * 32 + col] = acc[ms][ns][r];
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < GRP; ++i) {
+      const int item = tid + 256 * i;          // 256 voxels x GRP groups
+      const int vl = item / GRP, grp = item % GRP;
+      const int gz = STEP * (z0 + 2 * half + (vl >> 7)) + pz, gy = STEP * (y0 + ((vl >> 5) & 3)) + py,
+                gx = STEP * (x0 + (vl & 31)) + px;
+      const int co0 = ntile * NCOL + grp * 8;
+      if (gz < a.D && gy < a.H && gx < a.W && co0 < a.cout) {
+        void* dpv = a.dst0; int dC = a.dstC0, dacc = a.dacc0, cl = co0;
+        if (co0 >= a.dcum2) { dpv = a.dst2; dC = a.dstC2; dacc = a.dacc2; cl = co0 - a.dcum2; }
+        else if (co0 >= a.dcum1) { dpv = a.dst1; dC = a.dstC1; dacc = a.dacc1; cl = co0 - a.dcum1; }
+        if (dpv != nullptr) {
+          float v[8];
+          load8(stage + vl * NCOL + grp * 8, v);
+          T* q = reinterpret_cast<T*>(dpv) + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * dC + cl;
+          store_vec8(q, v, dacc);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -271,13 +362,19 @@ int launch_conv_pack_weights(int dtype, const float* w, int taps, int cin_w, int
   return 0;
 }
 
-int conv_stats_tiles(Dims d) { return cdiv(d.D, CV_TZ) * cdiv(d.H, CV_TY) * cdiv(d.W, CV_TX); }
+// partial-stat slots per sample == workgroups per sample (tiles x parity classes of the dilation)
+int conv_stats_tiles(Dims d, int taps, int dil) {
+  const int st = taps == 27 ? dil : 1;
+  return cdiv(cdiv(d.D, st), CV_TZ) * cdiv(cdiv(d.H, st), CV_TY) * cdiv(cdiv(d.W, st), CV_TX) * st * st * st;
+}
 
 template <typename T, int NSUB, int TAPS, int DIL>
 static int launch_one(const ConvKArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int HALO = (TAPS == 27) ? DIL : 0;
+  constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int NVH = (CV_TZ + 2 * HALO) * (CV_TY + 2 * HALO) * (CV_TX + 2 * HALO);
-  constexpr int LDS = (NVH + TAPS * 32 * NSUB) * 32;
+  constexpr int LDS_K = (NVH + TAPS * 32 * NSUB) * 32;          // K-loop tiles
+  constexpr int LDS_E = 256 * 32 * NSUB * 4;                    // epilogue transpose stage
+  constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static bool configured = false;  // per instantiation
   if (!configured) {
     SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, NSUB, TAPS, DIL>),
@@ -327,10 +424,11 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   a.dcum2 = dst.n > 2 ? dst.C[0] + dst.C[1] : a.cout;
   a.stats = stats;
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
-  a.tx = cdiv(d.W, CV_TX); a.ty = cdiv(d.H, CV_TY); a.tz = cdiv(d.D, CV_TZ);
+  const int st = taps == 27 ? dil : 1;
+  a.tx = cdiv(cdiv(d.W, st), CV_TX); a.ty = cdiv(cdiv(d.H, st), CV_TY); a.tz = cdiv(cdiv(d.D, st), CV_TZ);
   a.nchunks = cdiv(a.cin, conv_kc(dtype));
   const int ncol = conv_ncol(a.cout);
-  dim3 grid(a.tx * a.ty * a.tz, cdiv(a.cout, ncol), d.N);
+  dim3 grid(a.tx * a.ty * a.tz * st * st * st, cdiv(a.cout, ncol), d.N);
   SEUNET_CHECK(d.N <= 65535, "conv: batch too large");
   if (dtype == SEUNET_BF16) return launch_t<bf16_t>(taps, dil, ncol / 32, a, grid, s);
   return launch_t<float>(taps, dil, ncol / 32, a, grid, s);

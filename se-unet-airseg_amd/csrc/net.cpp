@@ -193,7 +193,7 @@ struct Plan {
         gx_max = std::max(gx_max, act);
         wg_max = std::max(wg_max, wgrad_workspace_bytes(1, d.in_channel, r.cout));
       }
-      slots_max = std::max(slots_max, std::max(conv_stats_tiles(dims[lv]), epi_partials(dims[lv])));
+      slots_max = std::max(slots_max, std::max(std::max(conv_stats_tiles(dims[lv], 27, 1), conv_stats_tiles(dims[lv], 27, 2)), epi_partials(dims[lv])));
       cmax = std::max(cmax, r.cout);
     }
     stat_slots_max = slots_max;
@@ -273,7 +273,7 @@ struct Exec {
       if (int e = launch_conv_pack_weights(p.d.dtype, w, taps, cin, cout, 0, at(wp_off), s)) return e;
       mark("conv_fwd:" + nm);
       if (int e = launch_conv_igemm(p.d.dtype, taps, dil, src, cin, at(wp_off), bias, dst, dat(p.stats), dm, s)) return e;
-      slots = conv_stats_tiles(dm);
+      slots = conv_stats_tiles(dm, taps, dil);
     }
     mark("stats");
     return launch_stats_finalize(dat(p.stats), slots, cout, dm.N, dm.vox(), p.d.eps, 0, fat(mean_off), fat(rstd_off), s);

@@ -137,7 +137,7 @@ int launch_pack_cl(int dtype, const float* in_ncdhw, int C, void* out_cl, int Cp
 size_t conv_wpack_bytes(int dtype, int taps, int cin, int cout);
 int launch_conv_pack_weights(int dtype, const float* w_torch, int taps, int cin_w, int cout_w,
                              int transpose_flip, void* wpack, hipStream_t s);
-int conv_stats_tiles(Dims d);     // partial-stat slots per sample written by the igemm kernel
+int conv_stats_tiles(Dims d, int taps, int dil);   // partial-stat slots per sample written by the igemm kernel
 int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_logical,
                       const void* wpack, const float* bias, const DstList& dst,
                       double* stats_partial, Dims d, hipStream_t s);

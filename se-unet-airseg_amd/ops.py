@@ -89,7 +89,7 @@ def conv3d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[to
     wbuf = weight.contiguous().float() if impl == _lib.CONV_NAIVE else pack_weights(weight, code, transpose_flip)
     stats, slots = None, 0
     if want_stats:
-        slots = lib.seunet_conv_stats_slots(impl, dims)
+        slots = lib.seunet_conv_stats_slots(impl, taps, dilation, dims)
         stats = torch.zeros((dims.n, slots, sum(dst_channels), 2), dtype=torch.float64, device=srcs[0].device)
     b = None if bias is None else bias.contiguous().float()
     _lib.check(lib.seunet_conv3d_fwd(code, impl, taps, dilation, len(srcs), _lib.ptr_array(list(srcs)),
