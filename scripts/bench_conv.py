@@ -1,0 +1,59 @@
+"""Microbenchmark of single conv launches (fwd / dgrad / wgrad) on the heavy SE-UNet layer shapes."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import torch
+import seunet_amd
+from seunet_amd import ops as S, _lib
+
+B = int(os.environ.get("B", 4))
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+reps = int(os.environ.get("REPS", 5))
+# name, splits, cout, dil, size
+CASES = [("dc5", [32, 32], 32, 1, 128), ("dc3", [64, 64], 64, 1, 64), ("ec3", [16], 32, 2, 128), ("dc6", [32], 16, 1, 128),
+         ("ec2", [8], 16, 1, 128), ("ec6", [32], 64, 2, 64), ("dc4", [64], 32, 1, 64)]
+dt = torch.bfloat16
+for name, split, cout, dil, size in CASES:
+    if only and only != name:
+        continue
+    cin = sum(split)
+    srcs = [torch.randn((B, size, size, size, c), device="cuda", dtype=dt) for c in split]
+    w = torch.randn((cout, cin, 3, 3, 3), device="cuda") * 0.05
+    dy = torch.randn((B, size, size, size, cout), device="cuda", dtype=dt)
+    flops = 2.0 * 27 * cin * cout * B * size ** 3
+    def timeit(fn):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    lib = _lib.load()
+    code = _lib.BF16
+    wp = S.pack_weights(w, code, False)
+    wpd = S.pack_weights(w, code, True)
+    dims = _lib.Dims(B, size, size, size)
+    out = torch.empty((B, size, size, size, cout), device="cuda", dtype=dt)
+    slots = lib.seunet_conv_stats_slots(0, 27, dil, dims)
+    stats = torch.zeros((B, slots, cout, 2), dtype=torch.float64, device="cuda")
+    def fwd():
+        _lib.check(lib.seunet_conv3d_fwd(code, 0, 27, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, wp.data_ptr(), 0,
+                                         None, 1, _lib.ptr_array([out]), _lib.int_array([cout]), _lib.int_array([0]), stats.data_ptr(), dims, _lib.stream_ptr()))
+    gs = [torch.empty_like(s) for s in srcs]
+    def dgrad():
+        _lib.check(lib.seunet_conv3d_fwd(code, 0, 27, dil, 1, _lib.ptr_array([dy]), _lib.int_array([cout]), cout, wpd.data_ptr(), 1,
+                                         None, len(gs), _lib.ptr_array(gs), _lib.int_array(split), _lib.int_array([0] * len(gs)), None, dims, _lib.stream_ptr()))
+    nb = lib.seunet_conv3d_wgrad_workspace_bytes(27, cin, cout)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dw = torch.empty((cout, cin, 3, 3, 3), device="cuda")
+    def wgrad():
+        _lib.check(lib.seunet_conv3d_wgrad(code, 0, 27, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, dy.data_ptr(), cout,
+                                           dw.data_ptr(), ws.data_ptr(), nb, dims, _lib.stream_ptr()))
+    which = os.environ.get("WHICH", "fwd,dgrad,wgrad").split(",")
+    res = []
+    for nm, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+        if nm in which:
+            ms = timeit(fn)
+            res.append("%s %.3f ms %.0f TF/s" % (nm, ms, flops / ms / 1e9))
+    print("%-4s %s->%d d%d @%d^3 B%d: " % (name, split, cout, dil, size, B) + " | ".join(res), flush=True)

@@ -15,9 +15,12 @@
 //                 so a ds_read_b128 of 16 consecutive voxels is conflict-free; weight slab
 //                 [tap][k-half][column][8 x bf16] (one contiguous 16-B fragment per lane)
 //   K loop        chunks of 32 bytes of channels (16 bf16 / 8 f32).  The NEXT chunk's tile and weights are
-//                 fetched into registers (fully unrolled 16-B loads, all in flight) while the current
-//                 chunk's 27 taps of MFMAs run; they are written to LDS after the barrier (split
-//                 issue-early / write-late staging)
+//                 fetched into registers while the current chunk's 27 taps of MFMAs run, and written to LDS
+//                 after the barrier (split issue-early / write-late staging).  The fetches are
+//                 buffer_load_dwordx4 through wave-uniform descriptors: 32-bit offsets, and the hardware
+//                 range check returns zeros for padding voxels / channels, so there is no branch and no
+//                 64-bit address arithmetic in the loop (each wave fetches one 16-B piece index of 64
+//                 consecutive halo voxels per instruction)
 //   epilogue      + bias; per-(n,c) InstanceNorm partial sums in f64 from the f32 accumulators (wave shuffle +
 //                 fixed-order cross-wave sum); the tile is transposed through LDS so that every lane stores
 //                 16 B (8 channels of one voxel), optionally += (gradient accumulation) and split over up to
@@ -29,6 +32,7 @@ namespace seunet {
 
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int CV_TZ = 4, CV_TY = 4, CV_TX = 32;
 
@@ -79,12 +83,12 @@ conv_igemm_kernel(ConvKArgs a) {
   constexpr int NVH = HZ * HY * HX;
   constexpr int NCOL = 32 * NSUB;
   constexpr int T3 = (TAPS == 27) ? 3 : 1;
-  constexpr int IN_ITEMS = (NVH * 2 + 255) / 256;
+  constexpr int IN_ITEMS = (NVH * 2 + 255) / 256;           // 16-B pieces per thread (LDS region padded to IN_ITEMS*4 KB)
   constexpr int W_TOTAL = TAPS * NCOL * 2;                  // 16-byte pieces of one weight slab
   constexpr int W_ITEMS = (W_TOTAL + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* in_tile = smem;
-  unsigned char* w_tile = smem + NVH * 32;
+  unsigned char* w_tile = smem + IN_ITEMS * 4096;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
@@ -104,43 +108,51 @@ conv_igemm_kernel(ConvKArgs a) {
   const int ntile = blockIdx.y, n = blockIdx.z;
   const long long V = (long long)a.D * a.H * a.W;
 
-  // ---- per-thread staging plan: which halo voxels this thread fetches (chunk independent) ----
-  const int piece = tid & 1;
-  int voff[IN_ITEMS];
+  // ---- per-thread staging plan (chunk independent) ----
+  // staging slot L = tid + 256*k: wave-instruction (wave, k) moves piece (wave & 1) of the 64 consecutive halo
+  // voxels starting at (2k + (wave >> 1)) * 64, so the piece -- hence the source tensor -- is wave-uniform.
+  const int piece = wave & 1;
+  constexpr unsigned INVALID = 0xFFFFFFFFu;
+  unsigned vofs[IN_ITEMS];
 #pragma unroll
   for (int k = 0; k < IN_ITEMS; ++k) {
-    const int idx = tid + 256 * k;
-    const int vox = idx >> 1;
+    const int vox = (2 * k + (wave >> 1)) * 64 + lane;
     const int hx = vox % HX;
     const int r2 = vox / HX;
     const int hy = r2 % HY, hz = r2 / HY;
-    const int gz = STEP * (z0 - HALO + hz) + pz, gy = STEP * (y0 - HALO + hy) + py, gx = STEP * (x0 - HALO + hx) + px;
-    const bool ok = idx < NVH * 2 && (z0 - HALO + hz) >= 0 && (y0 - HALO + hy) >= 0 && (x0 - HALO + hx) >= 0 &&
-                    gz < a.D && gy < a.H && gx < a.W;
-    voff[k] = ok ? (gz * a.H + gy) * a.W + gx : -1;
+    const int lz = z0 - HALO + hz, ly = y0 - HALO + hy, lx = x0 - HALO + hx;
+    const int gz = STEP * lz + pz, gy = STEP * ly + py, gx = STEP * lx + px;
+    const bool ok = vox < NVH && lz >= 0 && ly >= 0 && lx >= 0 && gz < a.D && gy < a.H && gx < a.W;
+    vofs[k] = ok ? (unsigned)((gz * a.H + gy) * a.W + gx) : INVALID;
   }
-  const uint4* wbase = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.wpack) +
-                                                      (size_t)ntile * a.nchunks * (size_t)(W_TOTAL * 16));
-  uint4 rin[IN_ITEMS], rw[W_ITEMS];
+  const int lds_in0 = lane * 32 + (wave >> 1) * 2048 + 16 * (piece ^ ((lane >> 3) & 1));   // + k * 4096
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpack) +
+                               (size_t)ntile * a.nchunks * (size_t)(W_TOTAL * 16);
+  u32x4 rin[IN_ITEMS], rw[W_ITEMS];
+  auto uniform_ptr = [](const void* p) -> const void* {   // tell the compiler the descriptor base is wave-uniform
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+  };
   auto prefetch = [&](int chunk) {
     const int ch0 = chunk * KC + piece * (KC / 2);
     const void* sp = a.src0; int sC = a.srcC0, c = ch0;
     if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
     else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
     const T* base = reinterpret_cast<const T*>(sp) + (long long)n * V * sC + c;
-    const bool chv = ch0 < a.cin;
+    const long long avail = ch0 < a.cin ? ((long long)V * sC - c) * (long long)sizeof(T) : 0;   // 0 records: all zeros
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(uniform_ptr(base)), 0, __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
+    const unsigned stride = __builtin_amdgcn_readfirstlane((unsigned)(sC * (int)sizeof(T)));
 #pragma unroll
     for (int k = 0; k < IN_ITEMS; ++k) {
-      rin[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (chv && voff[k] >= 0) rin[k] = *reinterpret_cast<const uint4*>(base + (long long)voff[k] * sC);
+      const unsigned off = vofs[k] == INVALID ? 0xFFFFFFF0u : vofs[k] * stride;
+      rin[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
     }
-    const uint4* wsrc = wbase + (size_t)chunk * W_TOTAL;
+    const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(uniform_ptr(wbase + (size_t)chunk * (W_TOTAL * 16))), 0, W_TOTAL * 16, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < W_ITEMS; ++k) {
-      const int idx = tid + 256 * k;
-      rw[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (idx < W_TOTAL) rw[k] = wsrc[idx];
-    }
+    for (int k = 0; k < W_ITEMS; ++k) rw[k] = __builtin_amdgcn_raw_buffer_load_b128(rwd, (unsigned)(tid + 256 * k) * 16u, 0, 0);
   };
 
   f32x16 acc[4][NSUB];
@@ -155,16 +167,9 @@ conv_igemm_kernel(ConvKArgs a) {
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     __syncthreads();   // every wave is done reading the previous chunk's tiles
 #pragma unroll
-    for (int k = 0; k < IN_ITEMS; ++k) {
-      const int idx = tid + 256 * k;
-      const int vox = idx >> 1;
-      if (idx < NVH * 2) *reinterpret_cast<uint4*>(in_tile + vox * 32 + 16 * (piece ^ ((vox >> 3) & 1))) = rin[k];
-    }
+    for (int k = 0; k < IN_ITEMS; ++k) *reinterpret_cast<u32x4*>(in_tile + lds_in0 + k * 4096) = rin[k];
 #pragma unroll
-    for (int k = 0; k < W_ITEMS; ++k) {
-      const int idx = tid + 256 * k;
-      if (idx < W_TOTAL) reinterpret_cast<uint4*>(w_tile)[idx] = rw[k];
-    }
+    for (int k = 0; k < W_ITEMS; ++k) *reinterpret_cast<u32x4*>(w_tile + (tid + 256 * k) * 16) = rw[k];
     __syncthreads();
     if (chunk + 1 < a.nchunks) prefetch(chunk + 1);   // in flight while the MFMAs below run
 
@@ -226,16 +231,19 @@ conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
       const int gy = STEP * (y0 + ms) + py;
+      const bool rowok = a.stats != nullptr && cvalid && gz_w < a.D && gy < a.H;
+      float p1 = 0.f, p2 = 0.f;   // 16 values in f32, then into the f64 running sums
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gx = STEP * (x0 + (r & 3) + 8 * (r >> 2) + 4 * h) + px;
         const float val = acc[ms][ns][r] + bias;
         acc[ms][ns][r] = val;
-        if (a.stats != nullptr && cvalid && gz_w < a.D && gy < a.H && gx < a.W) {
-          s1[ns] += (double)val;
-          s2[ns] += (double)val * (double)val;
-        }
+        const float m = (rowok && gx < a.W) ? val : 0.f;
+        p1 += m;
+        p2 += m * m;
       }
+      s1[ns] += (double)p1;
+      s2[ns] += (double)p2;
     }
   }
   __syncthreads();   // all waves are done with the K-loop tiles; LDS is reused below
@@ -372,7 +380,7 @@ template <typename T, int NSUB, int TAPS, int DIL>
 static int launch_one(const ConvKArgs& a, dim3 grid, hipStream_t s) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int NVH = (CV_TZ + 2 * HALO) * (CV_TY + 2 * HALO) * (CV_TX + 2 * HALO);
-  constexpr int LDS_K = (NVH + TAPS * 32 * NSUB) * 32;          // K-loop tiles
+  constexpr int LDS_K = ((NVH * 2 + 255) / 256 + (TAPS * 64 * NSUB + 255) / 256) * 4096;   // K-loop tiles, padded to whole staging rounds
   constexpr int LDS_E = 256 * 32 * NSUB * 4;                    // epilogue transpose stage
   constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static bool configured = false;  // per instantiation
