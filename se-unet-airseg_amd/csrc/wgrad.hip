@@ -33,32 +33,44 @@ struct WgArgs {
   int co_tiles;
 };
 
-template <typename T, int DIL, int TAPS> struct WgTile;
-template <int TAPS> struct WgTile<bf16_t, 1, TAPS> { static constexpr int TZ = 2, TY = 4; };
-template <int TAPS> struct WgTile<bf16_t, 2, TAPS> { static constexpr int TZ = 2, TY = 4; };
-template <int TAPS> struct WgTile<float, 1, TAPS> { static constexpr int TZ = 2, TY = 4; };
-template <int TAPS> struct WgTile<float, 2, TAPS> { static constexpr int TZ = 1, TY = 2; };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// spatial tile (z, y; x is always 32) on the (sub-)lattice.  Dilation 2 runs on the 8 parity sub-lattices
+// (voxel = 2*lattice + parity), so the halo is one lattice voxel for every dilation.
+template <typename T> struct WgTile;
+template <> struct WgTile<bf16_t> { static constexpr int TZ = 2, TY = 4; };
+template <> struct WgTile<float> { static constexpr int TZ = 1, TY = 4; };
+
+__device__ __forceinline__ const void* wg_uniform_ptr(const void* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+}
 
 template <typename T, int TAPS, int DIL>
 __global__ void __launch_bounds__(256)
 wgrad_kernel(WgArgs a) {
-  constexpr int HALO = (TAPS == 27) ? DIL : 0;
-  constexpr int TZ = WgTile<T, DIL, TAPS>::TZ, TY = WgTile<T, DIL, TAPS>::TY, TX = 32;
+  constexpr int HALO = (TAPS == 27) ? 1 : 0;
+  constexpr int STEP = (TAPS == 27) ? DIL : 1;
+  constexpr int TZ = WgTile<T>::TZ, TY = WgTile<T>::TY, TX = 32;
   constexpr int HZ = TZ + 2 * HALO, HY = TY + 2 * HALO, HX = TX + 2 * HALO;
   constexpr int NVH = HZ * HY * HX, NVT = TZ * TY * TX;
   constexpr int EPP = 16 / sizeof(T);   // elements per 16-byte piece
-  constexpr int PPV = 32 / EPP;         // pieces per voxel (32 channels)
+  constexpr int PPV = 32 / EPP;         // pieces per voxel (32 channels): 4 (bf16) / 8 (f32)
+  constexpr int X_ITEMS = (NVH * PPV + 255) / 256, Y_ITEMS = (NVT * PPV + 255) / 256;
+  constexpr int XV_PAD = (X_ITEMS * 256) / PPV;   // voxels incl. staging padding
   constexpr int NT = (TAPS == 27) ? 7 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* xs = reinterpret_cast<T*>(smem);                       // [NVH][32]
-  T* ys = reinterpret_cast<T*>(smem) + (size_t)NVH * 32;    // [NVT][32]
+  T* xs = reinterpret_cast<T*>(smem);                          // [XV_PAD][32]
+  T* ys = reinterpret_cast<T*>(smem) + (size_t)XV_PAD * 32;    // [YV_PAD][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int combo = blockIdx.y;
   const int ci0 = (combo / a.co_tiles) * 32, co0 = (combo % a.co_tiles) * 32;
   const long long V = (long long)a.D * a.H * a.W;
-  const int tiles_per_sample = a.tx * a.ty * a.tz;
+  const int tiles_per_par = a.tx * a.ty * a.tz;
+  const int tiles_per_sample = tiles_per_par * STEP * STEP * STEP;
   const int total_tiles = tiles_per_sample * a.N;
 
   int tapoff[NT];
@@ -75,46 +87,76 @@ wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
 
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  // staging slot L = tid + 256*k -> 16-byte piece (L / 64) % PPV of voxel ((L / 64) / PPV) * 64 + lane: each
+  // wave-instruction moves ONE piece index (wave-uniform source tensor) of 64 consecutive tile voxels.
+  u32x4 rx[X_ITEMS], ry[Y_ITEMS];
+  auto prefetch = [&](int tile) {
     const int n = tile / tiles_per_sample;
     int t = tile % tiles_per_sample;
+    const int par = t / tiles_per_par; t %= tiles_per_par;
     const int bx = t % a.tx; t /= a.tx;
     const int by = t % a.ty;
     const int bz = t / a.ty;
+    const int px = par % STEP, py = (par / STEP) % STEP, pz = par / (STEP * STEP);
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
-    __syncthreads();
-    for (int idx = tid; idx < NVH * PPV; idx += 256) {
-      const int vox = idx / PPV, piece = idx % PPV;
+#pragma unroll
+    for (int k = 0; k < X_ITEMS; ++k) {
+      const int wi = wave + 4 * k;                 // wave-instruction index
+      const int piece = wi % PPV, vox = (wi / PPV) * 64 + lane;
       const int hx = vox % HX;
       const int r2 = vox / HX;
       const int hy = r2 % HY, hz = r2 / HY;
-      const int gz = z0 - HALO + hz, gy = y0 - HALO + hy, gx = x0 - HALO + hx;
-      const int ch0 = ci0 + piece * EPP;
-      uint4 val = make_uint4(0u, 0u, 0u, 0u);
-      if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
-          ch0 < a.cin) {
-        const void* sp = a.src0; int sC = a.srcC0, c = ch0;
-        if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
-        else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
-        val = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(sp) +
-              ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * sC + c);
-      }
-      *reinterpret_cast<uint4*>(xs + (size_t)vox * 32 + piece * EPP) = val;
+      const int lz = z0 - HALO + hz, ly = y0 - HALO + hy, lx = x0 - HALO + hx;
+      const int gz = STEP * lz + pz, gy = STEP * ly + py, gx = STEP * lx + px;
+      const bool ok = vox < NVH && lz >= 0 && ly >= 0 && lx >= 0 && gz < a.D && gy < a.H && gx < a.W;
+      const int ch0 = ci0 + piece * EPP;           // wave-uniform
+      const void* sp = a.src0; int sC = a.srcC0, c = ch0;
+      if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
+      else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
+      const T* base = reinterpret_cast<const T*>(sp) + (long long)n * V * sC + c;
+      const long long avail = ch0 < a.cin ? ((long long)V * sC - c) * (long long)sizeof(T) : 0;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<void*>(wg_uniform_ptr(base)), 0, __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
+      const unsigned stride = __builtin_amdgcn_readfirstlane((unsigned)(sC * (int)sizeof(T)));
+      const unsigned off = ok ? (unsigned)((gz * a.H + gy) * a.W + gx) * stride : 0xFFFFFFF0u;
+      rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
     }
-    for (int idx = tid; idx < NVT * PPV; idx += 256) {
-      const int vox = idx / PPV, piece = idx % PPV;
+#pragma unroll
+    for (int k = 0; k < Y_ITEMS; ++k) {
+      const int wi = wave + 4 * k;
+      const int piece = wi % PPV, vox = (wi / PPV) * 64 + lane;
       const int lx = vox % TX;
       const int r2 = vox / TX;
       const int ly = r2 % TY, lz = r2 / TY;
-      const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+      const int gz = STEP * (z0 + lz) + pz, gy = STEP * (y0 + ly) + py, gx = STEP * (x0 + lx) + px;
+      const bool ok = vox < NVT && gz < a.D && gy < a.H && gx < a.W;
       const int ch0 = co0 + piece * EPP;
-      uint4 val = make_uint4(0u, 0u, 0u, 0u);
-      if (gz < a.D && gy < a.H && gx < a.W && ch0 < a.cout)
-        val = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.dy) +
-              ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * a.cout + ch0);
-      *reinterpret_cast<uint4*>(ys + (size_t)vox * 32 + piece * EPP) = val;
+      const T* base = reinterpret_cast<const T*>(a.dy) + (long long)n * V * a.cout + ch0;
+      const long long avail = ch0 < a.cout ? ((long long)V * a.cout - ch0) * (long long)sizeof(T) : 0;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<void*>(wg_uniform_ptr(base)), 0, __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
+      const unsigned stride = (unsigned)(a.cout * (int)sizeof(T));
+      const unsigned off = ok ? (unsigned)((gz * a.H + gy) * a.W + gx) * stride : 0xFFFFFFF0u;
+      ry[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) prefetch(tile);
+  for (; tile < total_tiles; tile += gridDim.x) {
+    __syncthreads();   // previous tile's reads are done
+#pragma unroll
+    for (int k = 0; k < X_ITEMS; ++k) {
+      const int wi = wave + 4 * k;
+      *reinterpret_cast<u32x4*>(xs + (size_t)((wi / PPV) * 64 + lane) * 32 + (wi % PPV) * EPP) = rx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < Y_ITEMS; ++k) {
+      const int wi = wave + 4 * k;
+      *reinterpret_cast<u32x4*>(ys + (size_t)((wi / PPV) * 64 + lane) * 32 + (wi % PPV) * EPP) = ry[k];
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);   // in flight during the MFMAs
     for (int row = 0; row < TZ * TY; ++row) {
       if (TAPS == 1 && (row & 3) != wave) continue;   // 1x1x1: rows are split over the waves
       const int lz = row / TY, ly = row % TY;
@@ -220,9 +262,11 @@ size_t wgrad_workspace_bytes(int taps, int cin, int cout) {
 
 template <typename T, int TAPS, int DIL>
 static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int HALO = (TAPS == 27) ? DIL : 0;
-  constexpr int TZ = WgTile<T, DIL, TAPS>::TZ, TY = WgTile<T, DIL, TAPS>::TY;
-  constexpr int LDS = ((TZ + 2 * HALO) * (TY + 2 * HALO) * (32 + 2 * HALO) + TZ * TY * 32) * 32 * (int)sizeof(T);
+  constexpr int HALO = (TAPS == 27) ? 1 : 0;
+  constexpr int TZ = WgTile<T>::TZ, TY = WgTile<T>::TY;
+  constexpr int PPV = 32 / (16 / (int)sizeof(T));
+  constexpr int NVH = (TZ + 2 * HALO) * (TY + 2 * HALO) * (32 + 2 * HALO), NVT = TZ * TY * 32;
+  constexpr int LDS = ((NVH * PPV + 255) / 256 + (NVT * PPV + 255) / 256) * 4096;
   static bool configured = false;
   if (!configured) {
     SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL>),
@@ -232,12 +276,6 @@ static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
   wgrad_kernel<T, TAPS, DIL><<<grid, 256, LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;
-}
-
-template <typename T>
-static void wgrad_tile_dims(int taps, int dil, int& tz, int& ty) {
-  if (taps == 1 || dil == 1) { tz = WgTile<T, 1, 27>::TZ; ty = WgTile<T, 1, 27>::TY; }
-  else { tz = WgTile<T, 2, 27>::TZ; ty = WgTile<T, 2, 27>::TY; }
 }
 
 // x: input activation (may be a concatenation), cin_logical leading channels carry weights;
@@ -259,12 +297,13 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   a.dy = dy; a.cout = cout;
   a.slab = reinterpret_cast<float*>(workspace);
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
-  int tz, ty;
-  if (dtype == SEUNET_BF16) wgrad_tile_dims<bf16_t>(taps, dil, tz, ty); else wgrad_tile_dims<float>(taps, dil, tz, ty);
-  a.tx = cdiv(d.W, 32); a.ty = cdiv(d.H, ty); a.tz = cdiv(d.D, tz);
+  const int tz = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TZ : WgTile<float>::TZ;
+  const int ty = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TY : WgTile<float>::TY;
+  const int st = taps == 27 ? dil : 1;
+  a.tx = cdiv(cdiv(d.W, st), 32); a.ty = cdiv(cdiv(d.H, st), ty); a.tz = cdiv(cdiv(d.D, st), tz);
   a.co_tiles = cdiv(cout, 32);
   const int combos = cdiv(cin_logical, 32) * a.co_tiles;
-  const int G = wgrad_groups(taps, combos, a.tx * a.ty * a.tz * d.N);
+  const int G = wgrad_groups(taps, combos, a.tx * a.ty * a.tz * st * st * st * d.N);
   dim3 grid(G, combos);
   int e;
   if (dtype == SEUNET_BF16) {
