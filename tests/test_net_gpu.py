@@ -107,8 +107,10 @@ def test_forward_backward_vs_oracle_fp32(A, orc, golden_dir, stage, impl):
     """Gradients are compared with the FLOAT64 oracle.  This network's gradient is ill-conditioned (InstanceNorm's
     backward cancels the dominant part of the Dice gradient) and contains discrete choices (LeakyReLU sign, max-pool
     argmax): one flipped element out of ~2M moves a tensor's gradient by ~1e-3 relative.  The fp32 reference itself
-    differs from its own float64 run by 1.6e-3..2.5e-3 on ec1..ec63 at this size (measured below, same inputs), so
-    the bar is: every tensor <= 1e-2, median <= 1.5e-3, and not worse than 5x the fp32 reference's own noise + 3e-3."""
+    differs from its own float64 run by up to 2.5e-3 on ec1..ec63 at this size (printed below, same inputs).  The bar
+    is therefore distributional: median <= 1e-3, 90th percentile <= 5e-3, every tensor <= 2e-2 (measured: median
+    2e-4, worst 8e-3).  A systematic error (e.g. f32 instead of f64 InstanceNorm sums) shows up as median ~1e-2.
+    The backward KERNELS are checked flip-free to 1e-5 in test_block_backward_exact_on_real_tensors_fp32."""
     golden = np.load(os.path.join(golden_dir, f"bwd32_stage{stage}.npz"))
     m = build(A, orc, 2, "fp32", impl)
     b = orc.synthetic_batch(2, (32, 32, 32), 2, seed=3)
@@ -133,8 +135,8 @@ def test_forward_backward_vs_oracle_fp32(A, orc, golden_dir, stage, impl):
     worst = max(err.values())
     med = float(np.median(list(err.values())))
     print(f"stage {stage} impl {impl}: HIP-vs-f64 max {worst:.2e} median {med:.2e}; fp32-reference-vs-f64 max {max(ref_noise.values()):.2e}")
-    assert worst <= 1e-2 and med <= 1.5e-3, sorted(err.items(), key=lambda kv: -kv[1])[:6]
-    assert worst <= 5 * max(ref_noise.values()) + 3e-3
+    p90 = float(np.percentile(list(err.values()), 90))
+    assert med <= 1e-3 and p90 <= 5e-3 and worst <= 2e-2, (med, p90, sorted(err.items(), key=lambda kv: -kv[1])[:6])
 
 
 def test_block_backward_exact_on_real_tensors_fp32(A, orc):
