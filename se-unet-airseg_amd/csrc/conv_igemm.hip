@@ -347,11 +347,14 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int taps, int cin_
   }
 }
 
-static inline int conv_ncol(int cout_e) { return cout_e > 32 ? 64 : 32; }
+// N columns per workgroup.  64 columns (two MFMA column blocks per A fragment, one workgroup per CU) only pay when
+// the K loop is long; measured on MI355X (scripts/bench_conv.py): 32->64 channel convs run 20-25 % faster as two
+// 32-column workgroups per CU, 128->64 runs 10 % faster with 64 columns.
+static inline int conv_ncol(int cin_e, int cout_e) { return (cout_e > 32 && cin_e >= 64) ? 64 : 32; }
 static inline int conv_kc(int dtype) { return dtype == SEUNET_BF16 ? 16 : 8; }
 
 size_t conv_wpack_bytes(int dtype, int taps, int cin, int cout) {
-  const int ncol = conv_ncol(cout), ntiles = cdiv(cout, ncol), nchunks = cdiv(cin, conv_kc(dtype));
+  const int ncol = conv_ncol(cin, cout), ntiles = cdiv(cout, ncol), nchunks = cdiv(cin, conv_kc(dtype));
   return (size_t)ntiles * nchunks * taps * ncol * 32;
 }
 
@@ -359,7 +362,7 @@ int launch_conv_pack_weights(int dtype, const float* w, int taps, int cin_w, int
                              void* wpack, hipStream_t s) {
   SEUNET_CHECK(taps == 27 || taps == 1, "conv pack: taps=%d unsupported", taps);
   const int cin_e = tflip ? cout_w : cin_w, cout_e = tflip ? cin_w : cout_w;
-  const int ncol = conv_ncol(cout_e), nchunks = cdiv(cin_e, conv_kc(dtype));
+  const int ncol = conv_ncol(cin_e, cout_e), nchunks = cdiv(cin_e, conv_kc(dtype));
   const long long total = (long long)(conv_wpack_bytes(dtype, taps, cin_e, cout_e) / dtype_size(dtype));
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == SEUNET_BF16)
@@ -435,7 +438,7 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   const int st = taps == 27 ? dil : 1;
   a.tx = cdiv(cdiv(d.W, st), CV_TX); a.ty = cdiv(cdiv(d.H, st), CV_TY); a.tz = cdiv(cdiv(d.D, st), CV_TZ);
   a.nchunks = cdiv(a.cin, conv_kc(dtype));
-  const int ncol = conv_ncol(a.cout);
+  const int ncol = conv_ncol(a.cin, a.cout);
   dim3 grid(a.tx * a.ty * a.tz * st * st * st, cdiv(a.cout, ncol), d.N);
   SEUNET_CHECK(d.N <= 65535, "conv: batch too large");
   if (dtype == SEUNET_BF16) return launch_t<bf16_t>(taps, dil, ncol / 32, a, grid, s);

@@ -59,18 +59,16 @@ channel_stats_kernel(const T* __restrict__ t, int C, double* __restrict__ partia
   }
 }
 
-// one wave per (n, c): sums the f64 partial slots in a fixed order.
+// one 256-thread block per (n, c): sums the f64 partial slots in a fixed order.
 //   mode 0: (mean, rstd = 1/sqrt(biased var + eps))      [InstanceNorm3d forward]
 //   mode 1: (sum/count, sumsq/count)                     [the two means of the InstanceNorm backward]
 __global__ void __launch_bounds__(256)
 stats_finalize_kernel(const double* __restrict__ partial, int slots, int C, int N, double inv_count,
                       float eps, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + wave;  // (n, c)
-  if (idx >= N * C) return;
+  const int idx = blockIdx.x;  // (n, c)
   const int n = idx / C, c = idx % C;
   double s1 = 0.0, s2 = 0.0;
-  for (int p = lane; p < slots; p += 64) {
+  for (int p = threadIdx.x; p < slots; p += 256) {
     const double* q = partial + (((long long)n * slots + p) * C + c) * 2;
     s1 += q[0];
     s2 += q[1];
@@ -80,7 +78,12 @@ stats_finalize_kernel(const double* __restrict__ partial, int slots, int C, int 
     s1 += __shfl_xor(s1, off, 64);
     s2 += __shfl_xor(s2, off, 64);
   }
-  if (lane == 0) {
+  __shared__ double w1[4], w2[4];
+  if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = s1; w2[threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = ((w1[0] + w1[1]) + w1[2]) + w1[3];
+    s2 = ((w2[0] + w2[1]) + w2[2]) + w2[3];
     if (mode == 0) {
       const double mean = s1 * inv_count;
       double var = s2 * inv_count - mean * mean;
@@ -198,10 +201,13 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     hw1 = head.head_w[1] * dr1;
   }
   double sdx[8], sdxx[8];
+  float fdx[8], fdxx[8];   // f32 staging of the f64 sums, flushed every 8 voxels
   float awse[8], awse2[8], aw20[8], aw21[8], am1[8], am2[8];
+  int since_flush = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     sdx[j] = sdxx[j] = 0.0;
+    fdx[j] = fdxx[j] = 0.f;
     awse[j] = awse2[j] = aw20[j] = aw21[j] = 0.f;
     am1[j] = APPLY ? m1p[n * C + c0 + j] : 0.f;
     am2[j] = APPLY ? m2p[n * C + c0 + j] : 0.f;
@@ -280,13 +286,20 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       if (APPLY) {
         dxh[j] = rs[j] * (dxh[j] - am1[j] - xh[j] * am2[j]);
       } else {
-        sdx[j] += (double)dxh[j];
-        sdxx[j] += (double)dxh[j] * (double)xh[j];
+        fdx[j] += dxh[j];
+        fdxx[j] += dxh[j] * xh[j];
       }
     }
     if (APPLY) store8(dxhat_out + vi * C + c0, dxh);
+    else if (++since_flush == 8) {
+      since_flush = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sdx[j] += (double)fdx[j]; sdxx[j] += (double)fdxx[j]; fdx[j] = fdxx[j] = 0.f; }
+    }
   }
   if (APPLY) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sdx[j] += (double)fdx[j]; sdxx[j] += (double)fdxx[j]; }
 
   // ---- block reduction (fixed order) ----
   __shared__ double redd[4][16][16];
@@ -499,7 +512,7 @@ int launch_channel_stats(int dtype, const void* t, int C, double* partial, Dims 
 
 int launch_stats_finalize(const double* partial, int slots, int C, int N, long long count, float eps,
                           int mode, float* out_a, float* out_b, hipStream_t s) {
-  stats_finalize_kernel<<<cdiv(N * C, 4), 256, 0, s>>>(partial, slots, C, N, 1.0 / (double)count, eps,
+  stats_finalize_kernel<<<N * C, 256, 0, s>>>(partial, slots, C, N, 1.0 / (double)count, eps,
                                                       mode, out_a, out_b);
   SEUNET_LAUNCH_CHECK();
   return 0;

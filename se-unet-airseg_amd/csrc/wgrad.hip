@@ -47,8 +47,9 @@ __device__ __forceinline__ const void* wg_uniform_ptr(const void* p) {
   return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
 }
 
-template <typename T, int TAPS, int DIL>
-__global__ void __launch_bounds__(256)
+// NW = waves per workgroup: the 27 taps are dealt round-robin to the waves (NT = ceil(27/NW) accumulators each)
+template <typename T, int TAPS, int DIL, int NW>
+__global__ void __launch_bounds__(NW * 64)
 wgrad_kernel(WgArgs a) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int STEP = (TAPS == 27) ? DIL : 1;
@@ -57,9 +58,10 @@ wgrad_kernel(WgArgs a) {
   constexpr int NVH = HZ * HY * HX, NVT = TZ * TY * TX;
   constexpr int EPP = 16 / sizeof(T);   // elements per 16-byte piece
   constexpr int PPV = 32 / EPP;         // pieces per voxel (32 channels): 4 (bf16) / 8 (f32)
-  constexpr int X_ITEMS = (NVH * PPV + 255) / 256, Y_ITEMS = (NVT * PPV + 255) / 256;
-  constexpr int XV_PAD = (X_ITEMS * 256) / PPV;   // voxels incl. staging padding
-  constexpr int NT = (TAPS == 27) ? 7 : 1;
+  constexpr int NTHR = NW * 64;
+  constexpr int X_ITEMS = (NVH * PPV + NTHR - 1) / NTHR, Y_ITEMS = (NVT * PPV + NTHR - 1) / NTHR;
+  constexpr int XV_PAD = (X_ITEMS * NTHR) / PPV;   // voxels incl. staging padding
+  constexpr int NT = (TAPS == 27) ? (27 + NW - 1) / NW : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);                          // [XV_PAD][32]
   T* ys = reinterpret_cast<T*>(smem) + (size_t)XV_PAD * 32;    // [YV_PAD][32]
@@ -76,7 +78,7 @@ wgrad_kernel(WgArgs a) {
   int tapoff[NT];
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti) {
-    int tap = wave + 4 * ti;
+    int tap = wave + NW * ti;
     if (tap > TAPS - 1) tap = TAPS - 1;
     if (TAPS == 27) tapoff[ti] = (((tap / 9) * HALO) * HY + ((tap / 3) % 3) * HALO) * HX + (tap % 3) * HALO;
     else tapoff[ti] = 0;
@@ -87,7 +89,7 @@ wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
 
-  // staging slot L = tid + 256*k -> 16-byte piece (L / 64) % PPV of voxel ((L / 64) / PPV) * 64 + lane: each
+  // staging slot L = tid + NTHR*k -> 16-byte piece (L / 64) % PPV of voxel ((L / 64) / PPV) * 64 + lane: each
   // wave-instruction moves ONE piece index (wave-uniform source tensor) of 64 consecutive tile voxels.
   u32x4 rx[X_ITEMS], ry[Y_ITEMS];
   auto prefetch = [&](int tile) {
@@ -101,7 +103,7 @@ wgrad_kernel(WgArgs a) {
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
 #pragma unroll
     for (int k = 0; k < X_ITEMS; ++k) {
-      const int wi = wave + 4 * k;                 // wave-instruction index
+      const int wi = wave + NW * k;                // wave-instruction index
       const int piece = wi % PPV, vox = (wi / PPV) * 64 + lane;
       const int hx = vox % HX;
       const int r2 = vox / HX;
@@ -123,7 +125,7 @@ wgrad_kernel(WgArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < Y_ITEMS; ++k) {
-      const int wi = wave + 4 * k;
+      const int wi = wave + NW * k;
       const int piece = wi % PPV, vox = (wi / PPV) * 64 + lane;
       const int lx = vox % TX;
       const int r2 = vox / TX;
@@ -147,18 +149,18 @@ wgrad_kernel(WgArgs a) {
     __syncthreads();   // previous tile's reads are done
 #pragma unroll
     for (int k = 0; k < X_ITEMS; ++k) {
-      const int wi = wave + 4 * k;
+      const int wi = wave + NW * k;
       *reinterpret_cast<u32x4*>(xs + (size_t)((wi / PPV) * 64 + lane) * 32 + (wi % PPV) * EPP) = rx[k];
     }
 #pragma unroll
     for (int k = 0; k < Y_ITEMS; ++k) {
-      const int wi = wave + 4 * k;
+      const int wi = wave + NW * k;
       *reinterpret_cast<u32x4*>(ys + (size_t)((wi / PPV) * 64 + lane) * 32 + (wi % PPV) * EPP) = ry[k];
     }
     __syncthreads();
     if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);   // in flight during the MFMAs
     for (int row = 0; row < TZ * TY; ++row) {
-      if (TAPS == 1 && (row & 3) != wave) continue;   // 1x1x1: rows are split over the waves
+      if (TAPS == 1 && (row % NW) != wave) continue;   // 1x1x1: rows are split over the waves
       const int lz = row / TY, ly = row % TY;
       const int xrow = ((lz * HY + ly) * HX) * 32;      // tap (0,0,0) row start in the halo tile
       const int yrow = (row * TX) * 32;
@@ -202,7 +204,7 @@ wgrad_kernel(WgArgs a) {
     float* out = a.slab + ((size_t)combo * gridDim.x + blockIdx.x) * (27 * 1024);
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
-      const int tap = wave + 4 * ti;
+      const int tap = wave + NW * ti;
       if (tap < 27) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -212,7 +214,7 @@ wgrad_kernel(WgArgs a) {
       }
     }
   } else {
-    float* out = a.slab + (((size_t)combo * gridDim.x + blockIdx.x) * 4 + wave) * 1024;
+    float* out = a.slab + (((size_t)combo * gridDim.x + blockIdx.x) * NW + wave) * 1024;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -260,20 +262,21 @@ size_t wgrad_workspace_bytes(int taps, int cin, int cout) {
   return (size_t)combos * g * (taps == 27 ? 27 : 4) * 1024 * sizeof(float);
 }
 
-template <typename T, int TAPS, int DIL>
+template <typename T, int TAPS, int DIL, int NW>
 static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int TZ = WgTile<T>::TZ, TY = WgTile<T>::TY;
   constexpr int PPV = 32 / (16 / (int)sizeof(T));
+  constexpr int NTHR = NW * 64;
   constexpr int NVH = (TZ + 2 * HALO) * (TY + 2 * HALO) * (32 + 2 * HALO), NVT = TZ * TY * 32;
-  constexpr int LDS = ((NVH * PPV + 255) / 256 + (NVT * PPV + 255) / 256) * 4096;
+  constexpr int LDS = ((NVH * PPV + NTHR - 1) / NTHR + (NVT * PPV + NTHR - 1) / NTHR) * NTHR * 16;
   static bool configured = false;
   if (!configured) {
-    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL>),
+    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     configured = true;
   }
-  wgrad_kernel<T, TAPS, DIL><<<grid, 256, LDS, s>>>(a);
+  wgrad_kernel<T, TAPS, DIL, NW><<<grid, NW * 64, LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -307,13 +310,15 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   dim3 grid(G, combos);
   int e;
   if (dtype == SEUNET_BF16) {
-    if (taps == 1) e = wgrad_launch_one<bf16_t, 1, 1>(a, grid, s);
-    else if (dil == 1) e = wgrad_launch_one<bf16_t, 27, 1>(a, grid, s);
-    else e = wgrad_launch_one<bf16_t, 27, 2>(a, grid, s);
+    if (taps == 1) e = wgrad_launch_one<bf16_t, 1, 1, 4>(a, grid, s);
+    // measured (scripts/bench_conv.py): single-combo layers run ~10 % faster with 8 waves (4 taps per wave),
+    // multi-combo layers with 4 waves (7 taps per wave, dY fragments amortised over more MFMAs)
+    else if (dil == 1) e = combos == 1 ? wgrad_launch_one<bf16_t, 27, 1, 8>(a, grid, s) : wgrad_launch_one<bf16_t, 27, 1, 4>(a, grid, s);
+    else e = combos == 1 ? wgrad_launch_one<bf16_t, 27, 2, 8>(a, grid, s) : wgrad_launch_one<bf16_t, 27, 2, 4>(a, grid, s);
   } else {
-    if (taps == 1) e = wgrad_launch_one<float, 1, 1>(a, grid, s);
-    else if (dil == 1) e = wgrad_launch_one<float, 27, 1>(a, grid, s);
-    else e = wgrad_launch_one<float, 27, 2>(a, grid, s);
+    if (taps == 1) e = wgrad_launch_one<float, 1, 1, 4>(a, grid, s);
+    else if (dil == 1) e = wgrad_launch_one<float, 27, 1, 4>(a, grid, s);
+    else e = wgrad_launch_one<float, 27, 2, 4>(a, grid, s);
   }
   if (e) return e;
   const int nslab = taps == 27 ? G : 4 * G;
