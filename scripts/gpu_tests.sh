@@ -6,6 +6,6 @@ echo "ops rc=$rc"; tail -3 gpurun_out/ops.log
 if [ $rc -le 1 ]; then
   timeout -k 10 900 python -m pytest tests/test_net_gpu.py -m gpu -q -s -p no:cacheprovider > gpurun_out/net.log 2>&1
   rc2=$?
-  echo "net rc=$rc2"; grep -E "HIP-vs-f64|bf16 logits|passed|failed|FAILED" gpurun_out/net.log | tail -20
+  echo "net rc=$rc2"; grep -E "HIP-vs-f64|gradient rel-L2|bf16 logits|passed|failed|FAILED" gpurun_out/net.log | tail -20
 fi
 exit 0

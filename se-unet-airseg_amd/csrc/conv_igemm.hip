@@ -232,18 +232,24 @@ conv_igemm_kernel(ConvKArgs a) {
     for (int ms = 0; ms < 4; ++ms) {
       const int gy = STEP * (y0 + ms) + py;
       const bool rowok = a.stats != nullptr && cvalid && gz_w < a.D && gy < a.H;
-      float p1 = 0.f, p2 = 0.f;   // 16 values in f32, then into the f64 running sums
+      // shifted sums: deviations from the row's first value are summed in f32 (no cancellation: they are of the
+      // order of the standard deviation), the shift is undone in f64
+      const float v0 = acc[ms][ns][0] + bias;
+      float p1 = 0.f, p2 = 0.f, cnt = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gx = STEP * (x0 + (r & 3) + 8 * (r >> 2) + 4 * h) + px;
         const float val = acc[ms][ns][r] + bias;
         acc[ms][ns][r] = val;
-        const float m = (rowok && gx < a.W) ? val : 0.f;
-        p1 += m;
-        p2 += m * m;
+        const bool ok = rowok && gx < a.W;
+        const float dv = ok ? val - v0 : 0.f;
+        p1 += dv;
+        p2 += dv * dv;
+        cnt += ok ? 1.f : 0.f;
       }
-      s1[ns] += (double)p1;
-      s2[ns] += (double)p2;
+      const double d0 = (double)v0, dp1 = (double)p1, dc = (double)cnt;
+      s1[ns] += dp1 + dc * d0;
+      s2[ns] += (double)p2 + 2.0 * d0 * dp1 + dc * d0 * d0;
     }
   }
   __syncthreads();   // all waves are done with the K-loop tiles; LDS is reused below

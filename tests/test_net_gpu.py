@@ -101,6 +101,18 @@ def _rel_errors(model, ref64):
     return out
 
 
+def _check_grad_noise(err, ref_noise):
+    """HIP-vs-float64 gradient errors must sit in the same noise band as the fp32 reference's own distance from its
+    float64 run on the same case (flip noise scales with 1/sqrt(#elements), so the band is case dependent):
+    median <= max(1e-3, 8 x ref), 90th percentile <= max(6e-3, 3 x ref), worst <= max(2e-2, 3 x ref)."""
+    v, r = np.array(list(err.values())), np.array(list(ref_noise.values()))
+    stats = (float(np.median(v)), float(np.percentile(v, 90)), float(v.max()))
+    ref = (float(np.median(r)), float(np.percentile(r, 90)), float(r.max()))
+    print("gradient rel-L2 vs f64 (median, p90, max): HIP %.2e %.2e %.2e | fp32 reference %.2e %.2e %.2e" % (stats + ref))
+    assert stats[0] <= max(1e-3, 8 * ref[0]) and stats[1] <= max(6e-3, 3 * ref[1]) and stats[2] <= max(2e-2, 3 * ref[2]), \
+        (stats, ref, sorted(err.items(), key=lambda kv: -kv[1])[:6])
+
+
 @pytest.mark.parametrize("stage", [1, 3])
 @pytest.mark.parametrize("impl", [0, 1])
 def test_forward_backward_vs_oracle_fp32(A, orc, golden_dir, stage, impl):
@@ -108,8 +120,8 @@ def test_forward_backward_vs_oracle_fp32(A, orc, golden_dir, stage, impl):
     backward cancels the dominant part of the Dice gradient) and contains discrete choices (LeakyReLU sign, max-pool
     argmax): one flipped element out of ~2M moves a tensor's gradient by ~1e-3 relative.  The fp32 reference itself
     differs from its own float64 run by up to 2.5e-3 on ec1..ec63 at this size (printed below, same inputs).  The bar
-    is therefore distributional: median <= 1e-3, 90th percentile <= 5e-3, every tensor <= 2e-2 (measured: median
-    2e-4, worst 8e-3).  A systematic error (e.g. f32 instead of f64 InstanceNorm sums) shows up as median ~1e-2.
+    is therefore distributional and relative to that measured reference noise (_check_grad_noise).  A systematic
+    error (e.g. f32 instead of f64 InstanceNorm sums) shows up as median ~1e-2, two orders above the band.
     The backward KERNELS are checked flip-free to 1e-5 in test_block_backward_exact_on_real_tensors_fp32."""
     golden = np.load(os.path.join(golden_dir, f"bwd32_stage{stage}.npz"))
     m = build(A, orc, 2, "fp32", impl)
@@ -135,8 +147,7 @@ def test_forward_backward_vs_oracle_fp32(A, orc, golden_dir, stage, impl):
     worst = max(err.values())
     med = float(np.median(list(err.values())))
     print(f"stage {stage} impl {impl}: HIP-vs-f64 max {worst:.2e} median {med:.2e}; fp32-reference-vs-f64 max {max(ref_noise.values()):.2e}")
-    p90 = float(np.percentile(list(err.values()), 90))
-    assert med <= 1e-3 and p90 <= 5e-3 and worst <= 2e-2, (med, p90, sorted(err.items(), key=lambda kv: -kv[1])[:6])
+    _check_grad_noise(err, ref_noise)
 
 
 def test_block_backward_exact_on_real_tensors_fp32(A, orc):
@@ -204,6 +215,28 @@ def test_reference_style_step_api_fp32(A, orc):
     for k in sd:                                                      # AdamW's sign-like first step: compare loosely
         assert float((sd[k].cpu() - so[k]).abs().max()) < 2.5e-4, k
     assert torch.equal(sd["dc62.conv1.weight"].cpu(), orc.deterministic_state_dict(2, 1, 1, 0)["dc62.conv1.weight"])
+
+
+def test_width_mult_2_forward_backward_fp32(A, orc):
+    """BASELINE configs[4] uses 2x channel width (a build-side extension; oracle = this repo's restatement)."""
+    m = A.SE_UNet(2, 1, width_mult=2, act_dtype="fp32")
+    m.load_state_dict(orc.deterministic_state_dict(2, 1, 2, seed=0))
+    m = m.cuda().eval()
+    o = orc.build_oracle(2, 1, 2, seed=0).double()
+    b = orc.synthetic_batch(1, (32, 32, 32), 2, seed=13)
+    pe, pd = o(b["image"].double())
+    l64 = orc.stage_loss(1, pe, pd, b["label"].double())
+    l64.backward()
+    ge, gd = m(b["image"].cuda())
+    assert float((gd.detach().cpu().double() - pd.detach()).abs().max()) < 1e-4
+    assert float((ge.detach().cpu().double() - pe.detach()).abs().max()) < 1e-4
+    loss = A.fused_stage_loss(1, ge, gd, b["label"].cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(l64.detach())) < 1e-5
+    o32 = orc.build_oracle(2, 1, 2, seed=0)
+    qe, qd = o32(b["image"])
+    orc.stage_loss(1, qe, qd, b["label"]).backward()
+    _check_grad_noise(_rel_errors(m, o), _rel_errors(o32, o))
 
 
 def test_noncontiguous_input_and_determinism_fp32(A, orc):
