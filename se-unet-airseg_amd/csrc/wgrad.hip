@@ -246,10 +246,11 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int taps, int cin
   if (ci < cin_w && co < cout_w) dw[((size_t)co * cin_w + ci) * taps + tap] = (float)((s0 + s1) + (s2 + s3));
 }
 
+// persistent workgroups per (ci, co) combo == slabs the reduce kernel has to sum; ~2 resident workgroups per CU in total
 static inline int wgrad_groups(int taps, int combos, int total_tiles) {
-  int g = 1024 / combos;
-  if (g < 32) g = 32;
-  if (g > 512) g = 512;
+  int g = 256 / combos;
+  if (g < 8) g = 8;
+  if (g > 256) g = 256;
   if (g > total_tiles) g = total_tiles;
   if (g < 1) g = 1;
   (void)taps;
@@ -258,7 +259,7 @@ static inline int wgrad_groups(int taps, int combos, int total_tiles) {
 
 size_t wgrad_workspace_bytes(int taps, int cin, int cout) {
   const int combos = cdiv(cin, 32) * cdiv(cout, 32);
-  const int g = 1024 / combos < 32 ? 32 : (1024 / combos > 512 ? 512 : 1024 / combos);
+  const int g = 256 / combos < 8 ? 8 : (256 / combos > 256 ? 256 : 256 / combos);
   return (size_t)combos * g * (taps == 27 ? 27 : 4) * 1024 * sizeof(float);
 }
 
