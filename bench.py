@@ -187,6 +187,15 @@ def main():
                 out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": (dom["gbs"] or 0.0) / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": dom["avg_ms"],
                                    "share_of_step": dom["share_of_step"]}
+        # HBM traffic of the dominant kernel from rocprofv3 PMC passes (scripts/pmc_traffic.sh -> profiles/r01_traffic.json:
+        # FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if dom is not None and "roofline" in out and os.path.exists(tpath) and B == 4 and S == 128 and args.dtype == "bf16":
+            rec = json.load(open(tpath))["kernels"].get(dom["kernel"])
+            if rec:
+                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "bytes per launch (PMC); algorithmic bytes per launch: %d" % int(
+                    algorithmic_work(dom["kernel"], table, esz)[1])
         out["kernels"] = kernels
         out["library_ms_per_step"] = lib_ms / args.steps
         flops_step = 3.0 * sum(c["flops"] for c in table.values())   # fwd + dgrad + wgrad (upper bound: ec1/x* have no dgrad)
