@@ -1,0 +1,47 @@
+"""Timing of the non-headline BASELINE.json configs on one GPU (for DESIGN.md; bench.py stays on configs[1])."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import torch
+import seunet_amd as A
+
+def sync_time(fn, reps):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+torch.manual_seed(0)
+# configs[3]: sliding-window whole-volume inference, 512^3, stride 64, 343 windows
+m = A.SE_UNet(2, 1, act_dtype="bf16").cuda().eval()
+x = torch.rand(1, 2, 512, 512, 512, device="cuda")
+for batch in (1, 4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = A.sliding_window_predict(m, x, 128, 64, batch=batch)
+    dt = time.perf_counter() - t0
+    print("configs[3] 512^3 stride 64 (343 windows, batch %d): %.2f s  -> %.1f M output voxels/s, %.1f M window-voxels/s, finite=%s"
+          % (batch, dt, 512 ** 3 / dt / 1e6, 343 * 128 ** 3 / dt / 1e6, bool(abs(out).max() < 1.0001)), flush=True)
+del x, out
+# forward-only window throughput
+xw = torch.rand(4, 2, 128, 128, 128, device="cuda")
+with torch.no_grad():
+    t = sync_time(lambda: m(xw), 5)
+print("forward only 4x128^3 bf16: %.2f ms -> %.1f M voxels/s" % (t * 1e3, 4 * 128 ** 3 / t / 1e6), flush=True)
+del m
+# configs[4] shape on one GPU: 2x width, 160^3, bf16 (fp16 storage is not implemented; same MFMA rate and bytes)
+for B in (1, 2):
+    m2 = A.SE_UNet(2, 1, width_mult=2, act_dtype="bf16").cuda().eval()
+    x2 = torch.rand(B, 2, 160, 160, 160, device="cuda")
+    lab = (torch.rand(B, 1, 160, 160, 160, device="cuda") < 0.03).float()
+    def step():
+        for p in m2.parameters():
+            p.grad = None
+        e, d = m2(x2)
+        A.fused_stage_loss(1, e, d, lab).backward()
+    t = sync_time(step, 3)
+    ok = all(torch.isfinite(p.grad).all() for n, p in m2.named_parameters() if not n.startswith("dc62."))
+    print("configs[4] shape: width x2, %dx160^3 bf16 fwd+bwd: %.1f ms -> %.1f M voxels/s (finite grads: %s, peak mem %.1f GB)"
+          % (B, t * 1e3, B * 160 ** 3 / t / 1e6, bool(ok), torch.cuda.max_memory_allocated() / 1e9), flush=True)
+    del m2, x2, lab

@@ -28,12 +28,11 @@ struct WgArgs {
   int cin;                 // logical input channels
   const void* dy; int cout;
   float* slab;
+  const void* zero;        // >= 16 zero bytes: source of padding voxels / channels for the LDS-DMA
   int N, D, H, W;
   int tx, ty, tz;          // tile counts per sample
   int co_tiles;
 };
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // spatial tile (z, y; x is always 32) on the (sub-)lattice.  Dilation 2 runs on the 8 parity sub-lattices
 // (voxel = 2*lattice + parity), so the halo is one lattice voxel for every dilation.
@@ -47,9 +46,14 @@ __device__ __forceinline__ const void* wg_uniform_ptr(const void* p) {
   return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
 }
 
-// NW = waves per workgroup: the 27 taps are dealt round-robin to the waves (NT = ceil(27/NW) accumulators each)
+// NW = waves per workgroup: the 27 taps are dealt round-robin to the waves (NT = ceil(27/NW) accumulators each).
+// Staging is LDS-DMA (global_load_lds_dwordx4): no staging registers and no ds_write phase, so two workgroups fit
+// on a CU and one computes while the other's tile is in flight.  The LDS image is planar,
+// [16-byte piece of the 32 channels][voxel][16 B]: one DMA wave-instruction writes 1 KB contiguous (64 consecutive
+// voxels of one piece, the piece -- hence the source tensor -- being wave-uniform); plane strides are = 64 (mod 256)
+// bytes so the transposing reads (4 voxels x 4 pieces per 32 lanes) touch every LDS bank once.
 template <typename T, int TAPS, int DIL, int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)   // two workgroups per CU
 wgrad_kernel(WgArgs a) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int STEP = (TAPS == 27) ? DIL : 1;
@@ -58,13 +62,15 @@ wgrad_kernel(WgArgs a) {
   constexpr int NVH = HZ * HY * HX, NVT = TZ * TY * TX;
   constexpr int EPP = 16 / sizeof(T);   // elements per 16-byte piece
   constexpr int PPV = 32 / EPP;         // pieces per voxel (32 channels): 4 (bf16) / 8 (f32)
-  constexpr int NTHR = NW * 64;
-  constexpr int X_ITEMS = (NVH * PPV + NTHR - 1) / NTHR, Y_ITEMS = (NVT * PPV + NTHR - 1) / NTHR;
-  constexpr int XV_PAD = (X_ITEMS * NTHR) / PPV;   // voxels incl. staging padding
+  constexpr int XG = (NVH + 63) / 64, YG = (NVT + 63) / 64;               // 64-voxel groups
+  constexpr int X_ITEMS = (XG * PPV + NW - 1) / NW, Y_ITEMS = (YG * PPV + NW - 1) / NW;   // DMA instructions per wave
+  constexpr int XPL = (XG * 64 + 4) * 16, YPL = (YG * 64 + 4) * 16;       // plane strides in bytes, = 64 (mod 256)
   constexpr int NT = (TAPS == 27) ? (27 + NW - 1) / NW : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* xs = reinterpret_cast<T*>(smem);                          // [XV_PAD][32]
-  T* ys = reinterpret_cast<T*>(smem) + (size_t)XV_PAD * 32;    // [YV_PAD][32]
+  unsigned char* xs = smem;                 // [PPV][XG*64 (+4)][16 B]
+  unsigned char* ys = smem + PPV * XPL;     // [PPV][YG*64 (+4)][16 B]
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
@@ -89,10 +95,8 @@ wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
 
-  // staging slot L = tid + NTHR*k -> 16-byte piece (L / 64) % PPV of voxel ((L / 64) / PPV) * 64 + lane: each
-  // wave-instruction moves ONE piece index (wave-uniform source tensor) of 64 consecutive tile voxels.
-  u32x4 rx[X_ITEMS], ry[Y_ITEMS];
-  auto prefetch = [&](int tile) {
+  // issue the DMA of one tile: wave-instruction index wi = wave + NW*k covers piece wi % PPV of voxel group wi / PPV
+  auto stage = [&](int tile) {
     const int n = tile / tiles_per_sample;
     int t = tile % tiles_per_sample;
     const int par = t / tiles_per_par; t %= tiles_per_par;
@@ -101,98 +105,85 @@ wgrad_kernel(WgArgs a) {
     const int bz = t / a.ty;
     const int px = par % STEP, py = (par / STEP) % STEP, pz = par / (STEP * STEP);
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
-#pragma unroll
+#pragma unroll 1   // keep the index arithmetic out of registers: it is recomputed per DMA instruction
     for (int k = 0; k < X_ITEMS; ++k) {
-      const int wi = wave + NW * k;                // wave-instruction index
-      const int piece = wi % PPV, vox = (wi / PPV) * 64 + lane;
-      const int hx = vox % HX;
-      const int r2 = vox / HX;
-      const int hy = r2 % HY, hz = r2 / HY;
-      const int lz = z0 - HALO + hz, ly = y0 - HALO + hy, lx = x0 - HALO + hx;
-      const int gz = STEP * lz + pz, gy = STEP * ly + py, gx = STEP * lx + px;
-      const bool ok = vox < NVH && lz >= 0 && ly >= 0 && lx >= 0 && gz < a.D && gy < a.H && gx < a.W;
-      const int ch0 = ci0 + piece * EPP;           // wave-uniform
-      const void* sp = a.src0; int sC = a.srcC0, c = ch0;
-      if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
-      else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
-      const T* base = reinterpret_cast<const T*>(sp) + (long long)n * V * sC + c;
-      const long long avail = ch0 < a.cin ? ((long long)V * sC - c) * (long long)sizeof(T) : 0;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<void*>(wg_uniform_ptr(base)), 0, __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
-      const unsigned stride = __builtin_amdgcn_readfirstlane((unsigned)(sC * (int)sizeof(T)));
-      const unsigned off = ok ? (unsigned)((gz * a.H + gy) * a.W + gx) * stride : 0xFFFFFFF0u;
-      rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      const int wi = wave + NW * k;
+      if (wi < XG * PPV) {                          // wave-uniform
+        const int piece = wi % PPV, vg = wi / PPV, vox = vg * 64 + lane;
+        const int hx = vox % HX;
+        const int r2 = vox / HX;
+        const int hy = r2 % HY, hz = r2 / HY;
+        const int lz = z0 - HALO + hz, ly = y0 - HALO + hy, lx = x0 - HALO + hx;
+        const int gz = STEP * lz + pz, gy = STEP * ly + py, gx = STEP * lx + px;
+        const int ch0 = ci0 + piece * EPP;
+        const bool ok = vox < NVH && lz >= 0 && ly >= 0 && lx >= 0 && gz < a.D && gy < a.H && gx < a.W && ch0 < a.cin;
+        const void* sp = a.src0; int sC = a.srcC0, c = ch0;
+        if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
+        else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
+        const T* g = ok ? reinterpret_cast<const T*>(sp) + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * sC + c
+                        : reinterpret_cast<const T*>(a.zero);
+        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(xs + piece * XPL + vg * 1024), 16, 0, 0);
+      }
     }
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < Y_ITEMS; ++k) {
       const int wi = wave + NW * k;
-      const int piece = wi % PPV, vox = (wi / PPV) * 64 + lane;
-      const int lx = vox % TX;
-      const int r2 = vox / TX;
-      const int ly = r2 % TY, lz = r2 / TY;
-      const int gz = STEP * (z0 + lz) + pz, gy = STEP * (y0 + ly) + py, gx = STEP * (x0 + lx) + px;
-      const bool ok = vox < NVT && gz < a.D && gy < a.H && gx < a.W;
-      const int ch0 = co0 + piece * EPP;
-      const T* base = reinterpret_cast<const T*>(a.dy) + (long long)n * V * a.cout + ch0;
-      const long long avail = ch0 < a.cout ? ((long long)V * a.cout - ch0) * (long long)sizeof(T) : 0;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<void*>(wg_uniform_ptr(base)), 0, __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
-      const unsigned stride = (unsigned)(a.cout * (int)sizeof(T));
-      const unsigned off = ok ? (unsigned)((gz * a.H + gy) * a.W + gx) * stride : 0xFFFFFFF0u;
-      ry[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      if (wi < YG * PPV) {
+        const int piece = wi % PPV, vg = wi / PPV, vox = vg * 64 + lane;
+        const int lx = vox % TX;
+        const int r2 = vox / TX;
+        const int ly = r2 % TY, lz = r2 / TY;
+        const int gz = STEP * (z0 + lz) + pz, gy = STEP * (y0 + ly) + py, gx = STEP * (x0 + lx) + px;
+        const int ch0 = co0 + piece * EPP;
+        const bool ok = vox < NVT && gz < a.D && gy < a.H && gx < a.W && ch0 < a.cout;
+        const T* g = ok ? reinterpret_cast<const T*>(a.dy) + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * a.cout + ch0
+                        : reinterpret_cast<const T*>(a.zero);
+        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(ys + piece * YPL + vg * 1024), 16, 0, 0);
+      }
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile < total_tiles) prefetch(tile);
-  for (; tile < total_tiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     __syncthreads();   // previous tile's reads are done
-#pragma unroll
-    for (int k = 0; k < X_ITEMS; ++k) {
-      const int wi = wave + NW * k;
-      *reinterpret_cast<u32x4*>(xs + (size_t)((wi / PPV) * 64 + lane) * 32 + (wi % PPV) * EPP) = rx[k];
-    }
-#pragma unroll
-    for (int k = 0; k < Y_ITEMS; ++k) {
-      const int wi = wave + NW * k;
-      *reinterpret_cast<u32x4*>(ys + (size_t)((wi / PPV) * 64 + lane) * 32 + (wi % PPV) * EPP) = ry[k];
-    }
-    __syncthreads();
-    if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);   // in flight during the MFMAs
+    stage(tile);
+    __syncthreads();   // (waits vmcnt(0): the DMA of every wave has landed)
     for (int row = 0; row < TZ * TY; ++row) {
       if (TAPS == 1 && (row % NW) != wave) continue;   // 1x1x1: rows are split over the waves
       const int lz = row / TY, ly = row % TY;
-      const int xrow = ((lz * HY + ly) * HX) * 32;      // tap (0,0,0) row start in the halo tile
-      const int yrow = (row * TX) * 32;
+      const int xrow = (lz * HY + ly) * HX;             // tap (0,0,0) voxel index of this row in the halo tile
+      const int yrow = row * TX;
       if constexpr (sizeof(T) == 2) {
         typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-        // lane -> (voxel, channel) piece of a 16-voxel x 32-channel operand: 16-lane group grp covers channels
-        // 16*(grp&1).. and voxels 8*(grp>>1)..+3 (second read: +4); lane li supplies row li>>2, columns 4*(li&3)..
+        // lane -> 8-byte chunk of a 16-voxel x 32-channel operand: 16-lane group grp covers channels 16*(grp&1).. and
+        // voxels 8*(grp>>1)..+3 (second read: +4); lane li supplies voxel li>>2, channels 4*(li&3)..+3
         const int grp = lane >> 4, li = lane & 15;
-        const int lane_off = (8 * (grp >> 1) + (li >> 2)) * 32 + 16 * (grp & 1) + 4 * (li & 3);
+        const int pl = 2 * (grp & 1) + ((li & 3) >> 1);                       // 16-byte piece (plane)
+        const int vo = 8 * (grp >> 1) + (li >> 2);                            // voxel within the 16-voxel step
+        const int sub = (li & 1) * 8;                                         // byte offset inside the piece
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          const bf16_t* yb = reinterpret_cast<const bf16_t*>(ys) + yrow + kk * 16 * 32 + lane_off;
+          const unsigned char* yb = ys + pl * YPL + (yrow + kk * 16 + vo) * 16 + sub;
           const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)yb);
-          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(yb + 4 * 32));
+          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(yb + 64));
           const bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int ti = 0; ti < NT; ++ti) {
-            const bf16_t* xa = reinterpret_cast<const bf16_t*>(xs) + xrow + (tapoff[ti] + kk * 16) * 32 + lane_off;
+            const unsigned char* xa = xs + pl * XPL + (xrow + tapoff[ti] + kk * 16 + vo) * 16 + sub;
             const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)xa);
-            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(xa + 4 * 32));
+            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(xa + 64));
             const bf16x8 afr = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
             acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
           }
         }
       } else {
+        const int pl = col >> 2, sub = (col & 3) * 4;   // f32: channel col lives in plane col/4
 #pragma unroll 4
         for (int kk = 0; kk < 16; ++kk) {
           const int xo = 2 * kk + h;
-          const float bfr = to_f32(ys[yrow + xo * 32 + col]);
+          const float bfr = *reinterpret_cast<const float*>(ys + pl * YPL + (yrow + xo) * 16 + sub);
 #pragma unroll
           for (int ti = 0; ti < NT; ++ti) {
-            const float afr = to_f32(xs[xrow + (tapoff[ti] + xo) * 32 + col]);
+            const float afr = *reinterpret_cast<const float*>(xs + pl * XPL + (xrow + tapoff[ti] + xo) * 16 + sub);
             acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr, bfr, acc[ti], 0, 0, 0);
           }
         }
@@ -248,9 +239,9 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int taps, int cin
 
 // persistent workgroups per (ci, co) combo == slabs the reduce kernel has to sum; ~2 resident workgroups per CU in total
 static inline int wgrad_groups(int taps, int combos, int total_tiles) {
-  int g = 256 / combos;
-  if (g < 8) g = 8;
-  if (g > 256) g = 256;
+  int g = 512 / combos;   // two resident workgroups per CU
+  if (g < 16) g = 16;
+  if (g > 512) g = 512;
   if (g > total_tiles) g = total_tiles;
   if (g < 1) g = 1;
   (void)taps;
@@ -259,8 +250,8 @@ static inline int wgrad_groups(int taps, int combos, int total_tiles) {
 
 size_t wgrad_workspace_bytes(int taps, int cin, int cout) {
   const int combos = cdiv(cin, 32) * cdiv(cout, 32);
-  const int g = 256 / combos < 8 ? 8 : (256 / combos > 256 ? 256 : 256 / combos);
-  return (size_t)combos * g * (taps == 27 ? 27 : 4) * 1024 * sizeof(float);
+  const int g = 512 / combos < 16 ? 16 : (512 / combos > 512 ? 512 : 512 / combos);
+  return 256 + (size_t)combos * g * (taps == 27 ? 27 : 4) * 1024 * sizeof(float);   // 256 zero bytes + slabs
 }
 
 template <typename T, int TAPS, int DIL, int NW>
@@ -268,9 +259,8 @@ static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int TZ = WgTile<T>::TZ, TY = WgTile<T>::TY;
   constexpr int PPV = 32 / (16 / (int)sizeof(T));
-  constexpr int NTHR = NW * 64;
   constexpr int NVH = (TZ + 2 * HALO) * (TY + 2 * HALO) * (32 + 2 * HALO), NVT = TZ * TY * 32;
-  constexpr int LDS = ((NVH * PPV + NTHR - 1) / NTHR + (NVT * PPV + NTHR - 1) / NTHR) * NTHR * 16;
+  constexpr int LDS = PPV * ((((NVH + 63) / 64) * 64 + 4) + (((NVT + 63) / 64) * 64 + 4)) * 16;
   static bool configured = false;
   if (!configured) {
     SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL, NW>),
@@ -299,7 +289,9 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   a.cum1 = x.n > 1 ? x.C[0] : x.total();
   a.cum2 = x.n > 2 ? x.C[0] + x.C[1] : x.total();
   a.dy = dy; a.cout = cout;
-  a.slab = reinterpret_cast<float*>(workspace);
+  a.zero = workspace;
+  a.slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + 256);
+  SEUNET_HIP(hipMemsetAsync(workspace, 0, 256, s));
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const int tz = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TZ : WgTile<float>::TZ;
   const int ty = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TY : WgTile<float>::TY;
@@ -312,10 +304,8 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   int e;
   if (dtype == SEUNET_BF16) {
     if (taps == 1) e = wgrad_launch_one<bf16_t, 1, 1, 4>(a, grid, s);
-    // measured (scripts/bench_conv.py): single-combo layers run ~10 % faster with 8 waves (4 taps per wave),
-    // multi-combo layers with 4 waves (7 taps per wave, dY fragments amortised over more MFMAs)
-    else if (dil == 1) e = combos == 1 ? wgrad_launch_one<bf16_t, 27, 1, 8>(a, grid, s) : wgrad_launch_one<bf16_t, 27, 1, 4>(a, grid, s);
-    else e = combos == 1 ? wgrad_launch_one<bf16_t, 27, 2, 8>(a, grid, s) : wgrad_launch_one<bf16_t, 27, 2, 4>(a, grid, s);
+    else if (dil == 1) e = wgrad_launch_one<bf16_t, 27, 1, 4>(a, grid, s);
+    else e = wgrad_launch_one<bf16_t, 27, 2, 4>(a, grid, s);
   } else {
     if (taps == 1) e = wgrad_launch_one<float, 1, 1, 4>(a, grid, s);
     else if (dil == 1) e = wgrad_launch_one<float, 27, 1, 4>(a, grid, s);
