@@ -79,7 +79,9 @@ def main():
     from seunet_amd import _lib, ddp
     import torch.distributed as dist
 
-    local = ddp.init_from_env("nccl")
+    # RCCL ("nccl") is the backend for real runs; SEUNET_DIST_BACKEND=gloo lets two ranks share one GPU for rehearsal
+    local = ddp.init_from_env(os.environ.get("SEUNET_DIST_BACKEND", "nccl"))
+    local = local % max(torch.cuda.device_count(), 1)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE is {world}"

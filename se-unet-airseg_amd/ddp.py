@@ -21,8 +21,8 @@ def init_from_env(backend: Optional[str] = None) -> int:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend)
     return local
 
