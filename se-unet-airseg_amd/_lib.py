@@ -10,7 +10,7 @@ import os
 from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseunet_hip.so")
+LIB_PATH = os.environ.get("SEUNET_LIB") or os.path.join(_HERE, "libseunet_hip.so")   # SEUNET_LIB: diagnostic builds only
 
 F32, BF16 = 0, 1
 CONV_MFMA, CONV_NAIVE = 0, 1

@@ -16,7 +16,12 @@ static int make_src(int nsrc, const void* const* src, const int* src_c, SrcList&
   return 0;
 }
 
+namespace seunet { extern unsigned long long* g_conv_debug; }
+
 extern "C" {
+
+// diagnostic hook (not part of the public header): device buffer of 8 u64 that -DSEUNET_STAMP builds add cycle sums to
+int seunet_debug_set_buffer(void* p) { seunet::g_conv_debug = reinterpret_cast<unsigned long long*>(p); return 0; }
 
 int seunet_version(void) { return 100; }
 const char* seunet_last_error(void) { return get_error(); }

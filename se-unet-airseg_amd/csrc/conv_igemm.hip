@@ -21,10 +21,11 @@
 //                 range check returns zeros for padding voxels / channels, so there is no branch and no
 //                 64-bit address arithmetic in the loop (each wave fetches one 16-B piece index of 64
 //                 consecutive halo voxels per instruction)
-//   epilogue      + bias; per-(n,c) InstanceNorm partial sums in f64 from the f32 accumulators (wave shuffle +
-//                 fixed-order cross-wave sum); the tile is transposed through LDS so that every lane stores
-//                 16 B (8 channels of one voxel), optionally += (gradient accumulation) and split over up to
-//                 three destination tensors (backward of the fused concatenation)
+//   epilogue      + bias; per-(n,c) InstanceNorm partial sums (shifted f32 sums per register row, f64 across rows,
+//                 fixed-order cross-wave sum); each wave transposes its own 128 voxels through a private LDS
+//                 stage (no workgroup barrier) so that every lane stores 16 B (8 channels of one voxel),
+//                 optionally += (gradient accumulation) and split over up to three destination tensors
+//                 (backward of the fused concatenation)
 //   grid          blockIdx.x is remapped so that each XCD (private L2) owns a contiguous run of tiles
 #include "seunet_common.h"
 
@@ -52,6 +53,7 @@ struct ConvKArgs {
   int N, D, H, W;
   int tx, ty, tz;            // tile counts (on the sub-lattice when dilated)
   int nchunks;
+  unsigned long long* debug;   // diagnostic builds only (-DSEUNET_STAMP): per-phase cycle sums
 };
 
 template <typename T> struct Frag;
@@ -73,9 +75,19 @@ __device__ __forceinline__ void store_vec8(bf16_t* q, const float (&v)[8], int a
   } else store8(q, v);
 }
 
+#ifdef SEUNET_STAMP
+#define STAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); ph[i] += _t - t_last; t_last = _t; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <typename T, int NSUB, int TAPS, int DIL>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(ConvKArgs a) {
+#ifdef SEUNET_STAMP
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
   constexpr int KC = Frag<T>::KC, KSTEPS = Frag<T>::KSTEPS;
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int STEP = (TAPS == 27) ? DIL : 1;              // voxel stride of the (sub-)lattice
@@ -164,14 +176,19 @@ conv_igemm_kernel(ConvKArgs a) {
       for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
   prefetch(0);
+  STAMP(0);   // prologue: index plan + first prefetch issue
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     __syncthreads();   // every wave is done reading the previous chunk's tiles
+    STAMP(1);   // barrier 1
 #pragma unroll
     for (int k = 0; k < IN_ITEMS; ++k) *reinterpret_cast<u32x4*>(in_tile + lds_in0 + k * 4096) = rin[k];
 #pragma unroll
     for (int k = 0; k < W_ITEMS; ++k) *reinterpret_cast<u32x4*>(w_tile + (tid + 256 * k) * 16) = rw[k];
+    STAMP(2);   // wait for the fetched registers + LDS writes
     __syncthreads();
+    STAMP(3);   // barrier 2
     if (chunk + 1 < a.nchunks) prefetch(chunk + 1);   // in flight while the MFMAs below run
+    STAMP(4);   // prefetch issue
 
     // ---- MFMA over taps ----
     for (int tz3 = 0; tz3 < T3; ++tz3) {
@@ -216,6 +233,7 @@ conv_igemm_kernel(ConvKArgs a) {
         }
       }
     }
+    STAMP(5);   // MFMA block of this chunk
   }
 
   // ---- epilogue ----
@@ -252,9 +270,14 @@ conv_igemm_kernel(ConvKArgs a) {
       s2[ns] += (double)p2 + 2.0 * d0 * dp1 + dc * d0 * d0;
     }
   }
+  STAMP(6);   // bias + statistics arithmetic
   __syncthreads();   // all waves are done with the K-loop tiles; LDS is reused below
+  STAMP(7);   // barrier after the K loop
+  // (2) statistics: per-wave partials through LDS, fixed-order sum.  This happens BEFORE the stores: a
+  //     __syncthreads() also waits for vmcnt(0), i.e. a barrier after the stores would wait for HBM write latency.
+  constexpr int STG = 64 * NCOL * 4;                       // bytes of one wave's transpose stage (64 voxels x NCOL f32)
+  double* red = reinterpret_cast<double*>(smem + 4 * STG);  // [4 waves][NCOL][2]
   if (a.stats != nullptr) {
-    double* red = reinterpret_cast<double*>(smem);  // [4][NCOL][2]
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
       const double u = s1[ns] + __shfl_xor(s1[ns], 32, 64);
@@ -274,46 +297,59 @@ conv_igemm_kernel(ConvKArgs a) {
         a.stats[(((long long)n * gridDim.x + tile_slot) * a.cout + co) * 2 + k] = tot;
       }
     }
-    __syncthreads();
   }
-  // (2) transpose through LDS in two halves (z-slices {0,1}, {2,3}) and store 8 channels (16/32 B) per lane
-  float* stage = reinterpret_cast<float*>(smem);   // [256 voxels][NCOL] f32
+  // (3) wave-private transpose (no workgroup barrier): two passes of 2 x-rows (64 voxels) through this wave's own
+  //     LDS stage, then every lane stores 8 channels (16/32 B) of one voxel
+  // store-phase destination of this lane (its 8-channel group is the same for every item): selected once
+  // (after the K loop, so it costs no registers there) so that no select chain / lookup table -- which the compiler
+  // would place in scratch and reload behind s_waitcnt vmcnt(0) -- sits between the global stores
   constexpr int GRP = NCOL / 8;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if ((wave >> 1) == half) {
-#pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns)
-#pragma unroll
-        for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int xl = (r & 3) + 8 * (r >> 2) + 4 * h;
-            stage[((((wave & 1) * 4 + ms) * 32 + xl) * NCOL) + ns * 32 + col] = acc[ms][ns][r];
-          }
+  T* sdst = nullptr; int sdC = 0, sdacc = 0;
+  {
+    const int co0 = ntile * NCOL + (lane % GRP) * 8;
+    if (co0 < a.cout) {
+      void* dpv = a.dst0; int cl = co0;
+      sdC = a.dstC0; sdacc = a.dacc0;
+      if (co0 >= a.dcum2) { dpv = a.dst2; sdC = a.dstC2; sdacc = a.dacc2; cl = co0 - a.dcum2; }
+      else if (co0 >= a.dcum1) { dpv = a.dst1; sdC = a.dstC1; sdacc = a.dacc1; cl = co0 - a.dcum1; }
+      if (dpv != nullptr) sdst = reinterpret_cast<T*>(dpv) + cl;
     }
-    __syncthreads();
+  }
+
+  float* stage = reinterpret_cast<float*>(smem + wave * STG);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int xl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          stage[(m2 * 32 + xl) * NCOL + ns * 32 + col] = acc[pass * 2 + m2][ns][r];
+        }
+    __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order
 #pragma unroll
     for (int i = 0; i < GRP; ++i) {
-      const int item = tid + 256 * i;          // 256 voxels x GRP groups
+      const int item = lane + 64 * i;            // 64 voxels x GRP groups; item % GRP == lane % GRP
       const int vl = item / GRP, grp = item % GRP;
-      const int gz = STEP * (z0 + 2 * half + (vl >> 7)) + pz, gy = STEP * (y0 + ((vl >> 5) & 3)) + py,
-                gx = STEP * (x0 + (vl & 31)) + px;
-      const int co0 = ntile * NCOL + grp * 8;
-      if (gz < a.D && gy < a.H && gx < a.W && co0 < a.cout) {
-        void* dpv = a.dst0; int dC = a.dstC0, dacc = a.dacc0, cl = co0;
-        if (co0 >= a.dcum2) { dpv = a.dst2; dC = a.dstC2; dacc = a.dacc2; cl = co0 - a.dcum2; }
-        else if (co0 >= a.dcum1) { dpv = a.dst1; dC = a.dstC1; dacc = a.dacc1; cl = co0 - a.dcum1; }
-        if (dpv != nullptr) {
-          float v[8];
-          load8(stage + vl * NCOL + grp * 8, v);
-          T* q = reinterpret_cast<T*>(dpv) + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * dC + cl;
-          store_vec8(q, v, dacc);
-        }
+      const int gy = STEP * (y0 + pass * 2 + (vl >> 5)) + py, gx = STEP * (x0 + (vl & 31)) + px;
+      if (sdst != nullptr && gz_w < a.D && gy < a.H && gx < a.W) {
+        float v[8];
+        load8(stage + vl * NCOL + grp * 8, v);
+        T* q = sdst + ((long long)n * V + ((long long)gz_w * a.H + gy) * a.W + gx) * sdC;
+        store_vec8(q, v, sdacc);
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
+#ifdef SEUNET_STAMP
+  STAMP(0);   // (added to slot 0) transpose + stores + final stats
+  if (a.debug != nullptr && lane == 0) {   // one 8-slot record per wave, no contention
+    const size_t w = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+    for (int i = 0; i < 8; ++i) a.debug[w * 8 + i] = ph[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -357,6 +393,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int taps, int cin_
 // the K loop is long; measured on MI355X (scripts/bench_conv.py): 32->64 channel convs run 20-25 % faster as two
 // 32-column workgroups per CU, 128->64 runs 10 % faster with 64 columns.
 static inline int conv_ncol(int cin_e, int cout_e) { return (cout_e > 32 && cin_e >= 64) ? 64 : 32; }
+unsigned long long* g_conv_debug = nullptr;   // set by seunet_debug_set_buffer (diagnostic builds)
 static inline int conv_kc(int dtype) { return dtype == SEUNET_BF16 ? 16 : 8; }
 
 size_t conv_wpack_bytes(int dtype, int taps, int cin, int cout) {
@@ -390,7 +427,7 @@ static int launch_one(const ConvKArgs& a, dim3 grid, hipStream_t s) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int NVH = (CV_TZ + 2 * HALO) * (CV_TY + 2 * HALO) * (CV_TX + 2 * HALO);
   constexpr int LDS_K = ((NVH * 2 + 255) / 256 + (TAPS * 64 * NSUB + 255) / 256) * 4096;   // K-loop tiles, padded to whole staging rounds
-  constexpr int LDS_E = 256 * 32 * NSUB * 4;                    // epilogue transpose stage
+  constexpr int LDS_E = 4 * 64 * 32 * NSUB * 4 + 4 * 32 * NSUB * 16;   // 4 wave-private transpose stages + stats partials
   constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static bool configured = false;  // per instantiation
   if (!configured) {
@@ -444,6 +481,7 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   const int st = taps == 27 ? dil : 1;
   a.tx = cdiv(cdiv(d.W, st), CV_TX); a.ty = cdiv(cdiv(d.H, st), CV_TY); a.tz = cdiv(cdiv(d.D, st), CV_TZ);
   a.nchunks = cdiv(a.cin, conv_kc(dtype));
+  a.debug = g_conv_debug;
   const int ncol = conv_ncol(a.cin, a.cout);
   dim3 grid(a.tx * a.ty * a.tz * st * st * st, cdiv(a.cout, ncol), d.N);
   SEUNET_CHECK(d.N <= 65535, "conv: batch too large");
