@@ -125,10 +125,16 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     hw0 = head.head_w[0] * (head.drop ? head.drop[n * head.drop_stride + 0] : 1.f);
     hw1 = head.head_w[1] * (head.drop ? head.drop[n * head.drop_stride + 1] : 1.f);
   }
-  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+  const long long stride = (long long)P * VPB;
+  long long v = (long long)blockIdx.x * VPB + vb;
+  Pack8<T> nx;   // software pipeline: voxel v + stride is loaded before voxel v is computed
+  zero8p(nx);
+  if (v < V) load8p(raw + ((long long)n * V + v) * C + c0, nx);
+  for (; v < V; v += stride) {
     const long long vi = (long long)n * V + v;
     float x[8], a[8], e[8];
-    load8(raw + vi * C + c0, x);
+    unpack8(nx, x);
+    if (v + stride < V) load8p(raw + (vi + stride) * C + c0, nx);
     float d1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -173,7 +179,7 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
 //   APPLY = true  (pass B): draw = rstd * (dxhat - m1 - xhat * m2), rounded once, stored over g_e
 // ----------------------------------------------------------------------------------
 template <typename T, int LPV, bool G2, bool APPLY>
-__global__ void __launch_bounds__(EPI_THREADS)
+__global__ void __launch_bounds__(EPI_THREADS, (APPLY || G2) ? 1 : 3)
 sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
                const float* __restrict__ rstd, int C, SseParams p, SseBwdIn g, SseHead head,
                const float* __restrict__ m1p, const float* __restrict__ m2p,
@@ -200,13 +206,15 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     hw0 = head.head_w[0] * dr0;
     hw1 = head.head_w[1] * dr1;
   }
-  double sdx[8], sdxx[8];
+  // f64 sums live in thread-private LDS slots (pass A only): 32 fewer VGPRs than register accumulators, which is
+  // the difference between 2 and 3 waves per SIMD for this latency-bound loop
+  __shared__ double acc64[APPLY ? 1 : 16][APPLY ? 1 : EPI_THREADS];
   float fdx[8], fdxx[8];   // f32 staging of the f64 sums, flushed every 8 voxels
   float awse[8], awse2[8], aw20[8], aw21[8], am1[8], am2[8];
   int since_flush = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sdx[j] = sdxx[j] = 0.0;
+    if (!APPLY) acc64[j][threadIdx.x] = acc64[8 + j][threadIdx.x] = 0.0;
     fdx[j] = fdxx[j] = 0.f;
     awse[j] = awse2[j] = aw20[j] = aw21[j] = 0.f;
     am1[j] = APPLY ? m1p[n * C + c0 + j] : 0.f;
@@ -214,10 +222,28 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   }
   float adb0 = 0.f, adb1 = 0.f, adh0 = 0.f, adh1 = 0.f;
 
-  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+  // software pipeline: the loads of voxel v + stride are issued before voxel v is computed
+  const long long stride = (long long)P * VPB;
+  long long v = (long long)blockIdx.x * VPB + vb;
+  Pack8<T> nx, nde;
+  float ngl = 0.f, ns0 = 0.f, ns1 = 0.f;
+  zero8p(nx); zero8p(nde);
+#define SSE_BWD_FETCH(vv)                                                                  \
+  do {                                                                                     \
+    const long long fi_ = (long long)n * V + (vv);                                         \
+    load8p(raw + fi_ * C + c0, nx);                                                        \
+    if (g.g_e) load8p(reinterpret_cast<const T*>(g.g_e) + fi_ * C + c0, nde);              \
+    if (g.g_level) ngl = g.g_level[fi_];                                                   \
+    else if (g.g_side) { ns0 = g.g_side[fi_ * 2]; ns1 = g.g_side[fi_ * 2 + 1]; }           \
+  } while (0)
+  if (v < V) SSE_BWD_FETCH(v);
+  for (; v < V; v += stride) {
     const long long vi = (long long)n * V + v;
     float x[8], xh[8], a[8], b[8], e[8], de[8];
-    load8(raw + vi * C + c0, x);
+    unpack8(nx, x);
+    unpack8(nde, de);
+    const float gl = ngl, gs0 = ns0, gs1 = ns1;
+    if (v + stride < V) SSE_BWD_FETCH(v + stride);
     float d1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -237,7 +263,6 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     // gradient arriving through the 2-channel side output
     float ds0 = 0.f, ds1 = 0.f;
     if (g.g_level) {
-      const float gl = g.g_level[vi];
       ds0 = hw0 * gl;
       ds1 = hw1 * gl;
       float s0 = 0.f, s1 = 0.f;
@@ -247,16 +272,10 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       s1 = group_sum<LPV>(s1) + b21;
       if (!APPLY && cg == 0) { adh0 += gl * dr0 * s0; adh1 += gl * dr1 * s1; }
     } else if (g.g_side) {
-      ds0 = g.g_side[vi * 2];
-      ds1 = g.g_side[vi * 2 + 1];
+      ds0 = gs0;
+      ds1 = gs1;
     }
     if (cg == 0) { adb0 += ds0; adb1 += ds1; }
-    if (g.g_e) {
-      load8(reinterpret_cast<const T*>(g.g_e) + vi * C + c0, de);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) de[j] = 0.f;
-    }
     float t2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -294,12 +313,21 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     else if (++since_flush == 8) {
       since_flush = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { sdx[j] += (double)fdx[j]; sdxx[j] += (double)fdxx[j]; fdx[j] = fdxx[j] = 0.f; }
+      for (int j = 0; j < 8; ++j) {
+        acc64[j][threadIdx.x] += (double)fdx[j];
+        acc64[8 + j][threadIdx.x] += (double)fdxx[j];
+        fdx[j] = fdxx[j] = 0.f;
+      }
     }
   }
+#undef SSE_BWD_FETCH
   if (APPLY) return;
+  double sdx[8], sdxx[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sdx[j] += (double)fdx[j]; sdxx[j] += (double)fdxx[j]; }
+  for (int j = 0; j < 8; ++j) {
+    sdx[j] = acc64[j][threadIdx.x] + (double)fdx[j];
+    sdxx[j] = acc64[8 + j][threadIdx.x] + (double)fdxx[j];
+  }
 
   // ---- block reduction (fixed order) ----
   __shared__ double redd[4][16][16];
@@ -381,17 +409,32 @@ cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     mu2[j] = TWO ? mean2[n * C + c0 + j] : 0.f;
     rs2[j] = TWO ? rstd2[n * C + c0 + j] : 0.f;
   }
-  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+  const long long stride = (long long)P * VPB;
+  long long v = (long long)blockIdx.x * VPB + vb;
+  Pack8<T> nx, nx2;   // software pipeline: voxel v + stride is loaded before voxel v is computed
+  zero8p(nx); zero8p(nx2);
+  if (v < V) {
     const long long o = ((long long)n * V + v) * C + c0;
-    float x[8], y[8];
-    load8(raw + o, x);
+    load8p(raw + o, nx);
+    if (TWO) load8p(raw2 + o, nx2);
+  }
+  for (; v < V; v += stride) {
+    const long long o = ((long long)n * V + v) * C + c0;
+    float x[8], x2[8], y[8];
+    unpack8(nx, x);
+    if (TWO) unpack8(nx2, x2);
+    if (v + stride < V) {
+      load8p(raw + o + stride * C, nx);
+      if (TWO) load8p(raw2 + o + stride * C, nx2);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (x[j] - mu[j]) * rs[j];
       y[j] = xh > 0.f ? xh : xh * slope;
     }
     if (TWO) {
-      load8(raw2 + o, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = x2[j];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xh = (x[j] - mu2[j]) * rs2[j];
@@ -431,11 +474,27 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
     b2[j] = (APPLY && TWO) ? m2bp[n * C + c0 + j] : 0.f;
     s[0][j] = s[1][j] = s[2][j] = s[3][j] = 0.0;
   }
-  for (long long v = (long long)blockIdx.x * VPB + vb; v < V; v += (long long)P * VPB) {
+  const long long stride = (long long)P * VPB;
+  long long v = (long long)blockIdx.x * VPB + vb;
+  Pack8<T> ng, nx, nx2;   // software pipeline: voxel v + stride is loaded before voxel v is computed
+  zero8p(ng); zero8p(nx); zero8p(nx2);
+  if (v < V) {
     const long long o = ((long long)n * V + v) * C + c0;
-    float gy[8], x[8], d[8];
-    load8(g_out + o, gy);
-    load8(raw + o, x);
+    load8p(g_out + o, ng);
+    load8p(raw + o, nx);
+    if (TWO) load8p(raw2 + o, nx2);
+  }
+  for (; v < V; v += stride) {
+    const long long o = ((long long)n * V + v) * C + c0;
+    float gy[8], x[8], x2[8], d[8];
+    unpack8(ng, gy);
+    unpack8(nx, x);
+    if (TWO) unpack8(nx2, x2);
+    if (v + stride < V) {   // a later voxel of this same thread: never written by anyone before it is read
+      load8p(g_out + o + stride * C, ng);
+      load8p(raw + o + stride * C, nx);
+      if (TWO) load8p(raw2 + o + stride * C, nx2);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (x[j] - mu[j]) * rs[j];
@@ -445,10 +504,9 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
     }
     if (TWO) {
       float d2[8];
-      load8(raw2 + o, x);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float xh = (x[j] - mu2[j]) * rs2[j];
+        const float xh = (x2[j] - mu2[j]) * rs2[j];
         d2[j] = gy[j] * (xh > 0.f ? 1.f : slope);
         if (APPLY) d2[j] = rs2[j] * (d2[j] - b1[j] - xh * b2[j]);
         else { s[2][j] += (double)d2[j]; s[3][j] += (double)d2[j] * (double)xh; }
@@ -521,7 +579,7 @@ int launch_stats_finalize(const double* partial, int slots, int C, int N, long l
 int launch_sse_fwd(int dtype, const void* raw, const float* mean, const float* rstd, int C,
                    const SseParams& p, void* e_out, const SseHead& head, Dims d, hipStream_t s) {
   if (int e = check_c(C)) return e;
-  dim3 grid(epi_partials(d), d.N);
+  dim3 grid(epi_partials(d) * 4, d.N);   // nothing is reduced here: enough blocks for full occupancy
   const bool g2 = p.w_se2 != nullptr;
   SEUNET_LPV_SWITCH(C / 8, {
     if (dtype == SEUNET_BF16) {

@@ -107,10 +107,41 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
   *reinterpret_cast<uint4*>(p) = u;
 }
 
-// sum over the LPV (power of two, <= 64) consecutive lanes that share one voxel
+// the same 8 channels kept packed (4 or 8 registers): what a software-pipelined loop carries for the NEXT voxel
+// while it computes the current one, so that two loads per lane are in flight instead of one
+template <typename T> struct Pack8;
+template <> struct Pack8<bf16_t> { uint4 u; };
+template <> struct Pack8<float> { float4 a, b; };
+__device__ __forceinline__ void load8p(const bf16_t* p, Pack8<bf16_t>& k) { k.u = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void load8p(const float* p, Pack8<float>& k) {
+  k.a = reinterpret_cast<const float4*>(p)[0];
+  k.b = reinterpret_cast<const float4*>(p)[1];
+}
+__device__ __forceinline__ void unpack8(const Pack8<bf16_t>& k, float (&v)[8]) {
+  v[0] = bf16_bits_to_f32(k.u.x & 0xffffu); v[1] = bf16_bits_to_f32(k.u.x >> 16);
+  v[2] = bf16_bits_to_f32(k.u.y & 0xffffu); v[3] = bf16_bits_to_f32(k.u.y >> 16);
+  v[4] = bf16_bits_to_f32(k.u.z & 0xffffu); v[5] = bf16_bits_to_f32(k.u.z >> 16);
+  v[6] = bf16_bits_to_f32(k.u.w & 0xffffu); v[7] = bf16_bits_to_f32(k.u.w >> 16);
+}
+__device__ __forceinline__ void unpack8(const Pack8<float>& k, float (&v)[8]) {
+  v[0] = k.a.x; v[1] = k.a.y; v[2] = k.a.z; v[3] = k.a.w; v[4] = k.b.x; v[5] = k.b.y; v[6] = k.b.z; v[7] = k.b.w;
+}
+__device__ __forceinline__ void zero8p(Pack8<bf16_t>& k) { k.u = make_uint4(0, 0, 0, 0); }
+__device__ __forceinline__ void zero8p(Pack8<float>& k) { k.a = k.b = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// sum over the LPV (power of two, <= 16) consecutive lanes that share one voxel, on DPP (data-parallel primitives:
+// a cross-lane operand fetched inside the VALU, a couple of cycles) instead of __shfl_xor (ds_bpermute: an LDS round
+// trip of ~100 cycles in a dependent chain).  quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies;
+// row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i) pair up the already reduced quads / octets.
+template <int CTRL> __device__ __forceinline__ float dpp_fetch(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int LPV> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int off = 1; off < LPV; off <<= 1) v += __shfl_xor(v, off, 64);
+  static_assert(LPV == 1 || LPV == 2 || LPV == 4 || LPV == 8 || LPV == 16, "group_sum: LPV must be 1..16");
+  if (LPV >= 2) v += dpp_fetch<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (LPV >= 4) v += dpp_fetch<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (LPV >= 8) v += dpp_fetch<0x141>(v);   // row_half_mirror
+  if (LPV >= 16) v += dpp_fetch<0x140>(v);  // row_mirror
   return v;
 }
 // sum over all lanes with the same (lane % LPV): the lanes holding the same channels
