@@ -53,18 +53,18 @@ for name, split, cout, dil, size in CASES:
     which = os.environ.get("WHICH", "fwd,dgrad,wgrad").split(",")
     if os.environ.get("SEUNET_STAMP"):
         import ctypes as C
-        dbg = torch.zeros(8 * 4 * 400000, dtype=torch.int64, device="cuda")
+        dbg = torch.zeros(12 * 4 * 400000, dtype=torch.int64, device="cuda")
         lib.seunet_debug_set_buffer.argtypes = [C.c_void_p]
         lib.seunet_debug_set_buffer(dbg.data_ptr())
-        names = ["prologue+stores", "barrier1", "regwait+ldswrite", "barrier2", "prefetch-issue", "mfma-block", "bias+stats", "barrier-after-K"]
+        names = ["first-prefetch", "barrier1", "regwait+ldswrite", "barrier2", "prefetch-issue", "mfma-block", "bias+stats", "barrier-after-K", "index-plan", "xwave-stats", "stage-writes", "stage-reads+stores"]
         for nm, fn in (("fwd", fwd), ("dgrad", dgrad)):
             if nm not in which:
                 continue
             fn(); torch.cuda.synchronize(); dbg.zero_(); fn(); torch.cuda.synchronize()
-            rec = dbg.view(-1, 8).double()
+            rec = dbg.view(-1, 12).double()
             used = rec.sum(1) > 0
             v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
-            print("  stamps %s %s: " % (name, nm) + "  ".join("%s %.1f%%" % (names[i], 100 * float(v[i]) / tot) for i in range(8)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
+            print("  stamps %s %s: " % (name, nm) + "  ".join("%s %.1f%%" % (names[i], 100 * float(v[i]) / tot) for i in range(12)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
     res = []
     for nm, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
         if nm in which:

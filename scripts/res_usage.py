@@ -3,7 +3,7 @@
 usage: scripts/res_usage.py <file.hip> <regex>"""
 import re, subprocess, sys, os
 src, pat = sys.argv[1], sys.argv[2]
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/tmp/_res.o",
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-c", src, "-o", "/tmp/_res.o",
                     "-I", os.path.join(os.path.dirname(os.path.abspath(src)), "../../include"),
                     "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
 for b in re.split(r"Function Name: ", r.stderr)[1:]:

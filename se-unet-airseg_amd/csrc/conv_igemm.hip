@@ -28,6 +28,7 @@
 //                 (backward of the fused concatenation)
 //   grid          blockIdx.x is remapped so that each XCD (private L2) owns a contiguous run of tiles
 #include "seunet_common.h"
+#include <utility>
 
 namespace seunet {
 
@@ -85,7 +86,7 @@ template <typename T, int NSUB, int TAPS, int DIL>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(ConvKArgs a) {
 #ifdef SEUNET_STAMP
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_readcyclecounter();
 #endif
   constexpr int KC = Frag<T>::KC, KSTEPS = Frag<T>::KSTEPS;
@@ -137,6 +138,7 @@ conv_igemm_kernel(ConvKArgs a) {
     const bool ok = vox < NVH && lz >= 0 && ly >= 0 && lx >= 0 && gz < a.D && gy < a.H && gx < a.W;
     vofs[k] = ok ? (unsigned)((gz * a.H + gy) * a.W + gx) : INVALID;
   }
+  STAMP(8);   // index plan
   const int lds_in0 = lane * 32 + (wave >> 1) * 2048 + 16 * (piece ^ ((lane >> 3) & 1));   // + k * 4096
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpack) +
                                (size_t)ntile * a.nchunks * (size_t)(W_TOTAL * 16);
@@ -146,25 +148,46 @@ conv_igemm_kernel(ConvKArgs a) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
   };
-  auto prefetch = [&](int chunk) {
+  // The fetch of one chunk is split into its descriptors (scalar work, once per chunk) and IN_ITEMS + W_ITEMS single
+  // wave-instructions, so that the K loop can issue them one per tap between the MFMAs: issued as one block they
+  // hold the wave for ~1.5k cycles (the texture path takes 16+ cycles per 1-KB instruction) with the matrix pipe idle.
+  __amdgpu_buffer_rsrc_t rs_in, rs_w;
+  unsigned in_stride = 0;
+  auto fetch_setup = [&](int chunk) __attribute__((always_inline)) {
     const int ch0 = chunk * KC + piece * (KC / 2);
     const void* sp = a.src0; int sC = a.srcC0, c = ch0;
     if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
     else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
     const T* base = reinterpret_cast<const T*>(sp) + (long long)n * V * sC + c;
     const long long avail = ch0 < a.cin ? ((long long)V * sC - c) * (long long)sizeof(T) : 0;   // 0 records: all zeros
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(uniform_ptr(base)), 0, __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
-    const unsigned stride = __builtin_amdgcn_readfirstlane((unsigned)(sC * (int)sizeof(T)));
-#pragma unroll
-    for (int k = 0; k < IN_ITEMS; ++k) {
-      const unsigned off = vofs[k] == INVALID ? 0xFFFFFFF0u : vofs[k] * stride;
-      rin[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(base)), 0,
+                                              __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
+    in_stride = __builtin_amdgcn_readfirstlane((unsigned)(sC * (int)sizeof(T)));
+    rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(wbase + (size_t)chunk * (W_TOTAL * 16))), 0,
+                                             W_TOTAL * 16, 0x00020000);
+  };
+  auto fetch_item = [&](auto item_c) __attribute__((always_inline)) {   // item: 0..IN_ITEMS-1 input pieces, then W_ITEMS weight pieces
+    constexpr int item = decltype(item_c)::value;
+    if constexpr (item < IN_ITEMS) {
+      // byte offset = voxel index x stride, formed at the point of issue from a fresh copy of the stride (the empty asm
+      // keeps the compiler from hoisting all IN_ITEMS products out of the tap loop into 10 more live registers).
+      // Padding voxels carry index 0xFFFFFFFF: the product wraps to 2^32 - stride, beyond any tensor the 32-bit range
+      // check admits (launch_conv_igemm rejects >= 2^31-byte samples), so the hardware returns zeros.
+      unsigned st = in_stride;
+      asm volatile("" : "+s"(st));
+      rin[item] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vofs[item] * st, 0, 0);
+    } else if constexpr (item < IN_ITEMS + W_ITEMS) {
+      constexpr int k = item - IN_ITEMS;
+      rw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)tid * 16u, k * 4096, 0);
     }
-    const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(uniform_ptr(wbase + (size_t)chunk * (W_TOTAL * 16))), 0, W_TOTAL * 16, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < W_ITEMS; ++k) rw[k] = __builtin_amdgcn_raw_buffer_load_b128(rwd, (unsigned)(tid + 256 * k) * 16u, 0, 0);
+  };
+  constexpr int F_ITEMS = IN_ITEMS + W_ITEMS;
+  constexpr int F_PER_TAP = (F_ITEMS + TAPS - 1) / TAPS;
+  auto fetch_range = [&](auto first_c) __attribute__((always_inline)) {   // items [first, first + F_PER_TAP)
+    constexpr int first = decltype(first_c)::value;
+    [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+      (fetch_item(std::integral_constant<int, first + I>{}), ...);
+    }(std::make_integer_sequence<int, F_PER_TAP>{});
   };
 
   f32x16 acc[4][NSUB];
@@ -175,7 +198,10 @@ conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
-  prefetch(0);
+  fetch_setup(0);
+  [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+    (fetch_item(std::integral_constant<int, I>{}), ...);
+  }(std::make_integer_sequence<int, F_ITEMS>{});
   STAMP(0);   // prologue: index plan + first prefetch issue
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     __syncthreads();   // every wave is done reading the previous chunk's tiles
@@ -187,16 +213,37 @@ conv_igemm_kernel(ConvKArgs a) {
     STAMP(2);   // wait for the fetched registers + LDS writes
     __syncthreads();
     STAMP(3);   // barrier 2
-    if (chunk + 1 < a.nchunks) prefetch(chunk + 1);   // in flight while the MFMAs below run
+    // Next chunk's fetch.  64 columns (one workgroup per CU, nothing else to fill the matrix pipe): issued one item
+    // per tap between the MFMAs below (measured -9..-11 % on 128->64 @64^3).  32 columns (two workgroups per CU): as
+    // one block here -- interleaved it ran 20 % slower (a wave blocked on a full vector-memory queue cannot issue
+    // its MFMAs either, while as a block the other workgroup's MFMAs cover the issue time).
+    constexpr bool INTERLEAVE = NSUB == 2;
+    const bool has_next = chunk + 1 < a.nchunks;
+    if (has_next) {
+      fetch_setup(chunk + 1);
+      if constexpr (!INTERLEAVE) {
+        [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+          (fetch_item(std::integral_constant<int, I>{}), ...);
+        }(std::make_integer_sequence<int, F_ITEMS>{});
+      }
+    }
     STAMP(4);   // prefetch issue
 
     // ---- MFMA over taps ----
+    constexpr int ZUNROLL = NSUB == 2 ? T3 : 1;
+    // 32 columns: the z loop stays rolled (fully unrolled the scheduler hoists LDS reads and the kernel no longer fits
+    // two workgroups per CU); 64 columns run one workgroup per CU anyway and compile without scratch only unrolled
+#pragma unroll ZUNROLL
     for (int tz3 = 0; tz3 < T3; ++tz3) {
-#pragma unroll
-      for (int ty3 = 0; ty3 < T3; ++ty3) {
-#pragma unroll
-        for (int tx3 = 0; tx3 < T3; ++tx3) {
-          const int tap = (tz3 * T3 + ty3) * T3 + tx3;
+     [&]<int... TYX>(std::integer_sequence<int, TYX...>) __attribute__((always_inline)) {
+      ([&]() __attribute__((always_inline)) {
+          constexpr int ty3 = TYX / T3, tx3 = TYX % T3;
+          const int tap = tz3 * T3 * T3 + TYX;
+          if (INTERLEAVE && has_next) {   // wave-uniform: the fetch items of this tap, with compile-time register indices
+            if (tz3 == 0) fetch_range(std::integral_constant<int, TYX * F_PER_TAP>{});
+            else if (tz3 == 1) fetch_range(std::integral_constant<int, (T3 * T3 + TYX) * F_PER_TAP>{});
+            else fetch_range(std::integral_constant<int, (2 * T3 * T3 + TYX) * F_PER_TAP>{});
+          }
           const int vbase = ((wave + tz3 * HALO) * HY + ty3 * HALO) * HX + tx3 * HALO + col;
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -230,8 +277,8 @@ conv_igemm_kernel(ConvKArgs a) {
               }
             }
           }
-        }
-      }
+      }(), ...);
+     }(std::make_integer_sequence<int, T3 * T3>{});
     }
     STAMP(5);   // MFMA block of this chunk
   }
@@ -298,6 +345,7 @@ conv_igemm_kernel(ConvKArgs a) {
       }
     }
   }
+  STAMP(9);   // cross-wave statistics
   // (3) wave-private transpose (no workgroup barrier): two passes of 2 x-rows (64 voxels) through this wave's own
   //     LDS stage, then every lane stores 8 channels (16/32 B) of one voxel
   // store-phase destination of this lane (its 8-channel group is the same for every item): selected once
@@ -329,6 +377,7 @@ conv_igemm_kernel(ConvKArgs a) {
           stage[(m2 * 32 + xl) * NCOL + ns * 32 + col] = acc[pass * 2 + m2][ns][r];
         }
     __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order
+    STAMP(10);   // transpose: stage writes
 #pragma unroll
     for (int i = 0; i < GRP; ++i) {
       const int item = lane + 64 * i;            // 64 voxels x GRP groups; item % GRP == lane % GRP
@@ -344,10 +393,10 @@ conv_igemm_kernel(ConvKArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
 #ifdef SEUNET_STAMP
-  STAMP(0);   // (added to slot 0) transpose + stores + final stats
-  if (a.debug != nullptr && lane == 0) {   // one 8-slot record per wave, no contention
+  STAMP(11);   // transpose: stage reads + global stores
+  if (a.debug != nullptr && lane == 0) {   // one 12-slot record per wave, no contention
     const size_t w = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
-    for (int i = 0; i < 8; ++i) a.debug[w * 8 + i] = ph[i];
+    for (int i = 0; i < 12; ++i) a.debug[w * 12 + i] = ph[i];
   }
 #endif
 }
@@ -485,6 +534,11 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   const int ncol = conv_ncol(a.cin, a.cout);
   dim3 grid(a.tx * a.ty * a.tz * st * st * st, cdiv(a.cout, ncol), d.N);
   SEUNET_CHECK(d.N <= 65535, "conv: batch too large");
+  // the staging loads use 32-bit byte offsets inside one sample of one source tensor
+  for (int i = 0; i < src.n; ++i)
+    SEUNET_CHECK((long long)d.vox() * src.C[i] * (long long)dtype_size(dtype) < (1LL << 31),
+                 "conv: one sample of source %d is %lld bytes; the MFMA path addresses < 2^31 bytes per sample "
+                 "(tile the volume, e.g. sliding_window_predict)", i, (long long)d.vox() * src.C[i] * (long long)dtype_size(dtype));
   if (dtype == SEUNET_BF16) return launch_t<bf16_t>(taps, dil, ncol / 32, a, grid, s);
   return launch_t<float>(taps, dil, ncol / 32, a, grid, s);
 }
