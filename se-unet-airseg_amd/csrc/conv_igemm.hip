@@ -29,6 +29,7 @@
 //   grid          blockIdx.x is remapped so that each XCD (private L2) owns a contiguous run of tiles
 #include "seunet_common.h"
 #include <utility>
+#include <type_traits>
 
 namespace seunet {
 
@@ -54,6 +55,7 @@ struct ConvKArgs {
   int N, D, H, W;
   int tx, ty, tz;            // tile counts (on the sub-lattice when dilated)
   int nchunks;
+  int direct;                // 1: every destination has <= 16 channels (stores straight from the accumulators)
   unsigned long long* debug;   // diagnostic builds only (-DSEUNET_STAMP): per-phase cycle sums
 };
 
@@ -61,19 +63,22 @@ template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { static constexpr int KC = 16, KSTEPS = 1; };
 template <> struct Frag<float> { static constexpr int KC = 8, KSTEPS = 4; };
 
-__device__ __forceinline__ void store_vec8(float* q, const float (&v)[8], int acc) {
-  if (acc) { float o[8]; load8(q, o);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] += v[j];
-    store8(q, o);
-  } else store8(q, v);
+// cross-lane fetches for f32 and f64 values: DPP (row-local patterns) and ds_swizzle xor 16 (within 32 lanes)
+template <int CTRL> __device__ __forceinline__ float xlane_dpp(float v) { return dpp_fetch<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ double xlane_dpp(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ void store_vec8(bf16_t* q, const float (&v)[8], int acc) {
-  if (acc) { float o[8]; load8(q, o);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] += v[j];
-    store8(q, o);
-  } else store8(q, v);
+__device__ __forceinline__ float xlane_swz16(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ double xlane_swz16(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, 0x401F);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), 0x401F);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 #ifdef SEUNET_STAMP
@@ -83,7 +88,7 @@ __device__ __forceinline__ void store_vec8(bf16_t* q, const float (&v)[8], int a
 #endif
 
 template <typename T, int NSUB, int TAPS, int DIL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (TAPS == 1 && NSUB == 1) ? 3 : 1)   // 1x1x1 is bandwidth bound: keep 3 workgroups per CU
 conv_igemm_kernel(ConvKArgs a) {
 #ifdef SEUNET_STAMP
   unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -259,7 +264,7 @@ conv_igemm_kernel(ConvKArgs a) {
                     *reinterpret_cast<const bf16x8*>(in_tile + vox * 32 + 16 * (h ^ ((vox >> 3) & 1)));
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns)
-                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[ns], acc[ms][ns], 0, 0, 0);
+                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ns], afr, acc[ms][ns], 0, 0, 0);
               }
             } else {
               float bfr[NSUB];
@@ -273,7 +278,7 @@ conv_igemm_kernel(ConvKArgs a) {
                     in_tile + vox * 32 + 16 * ((ks >> 1) ^ ((vox >> 3) & 1)) + 4 * (2 * (ks & 1) + h));
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns)
-                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr, bfr[ns], acc[ms][ns], 0, 0, 0);
+                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[ns], afr, acc[ms][ns], 0, 0, 0);
               }
             }
           }
@@ -284,57 +289,252 @@ conv_igemm_kernel(ConvKArgs a) {
   }
 
   // ---- epilogue ----
-  // (1) bias + f64 InstanceNorm partial sums from the accumulators
+  // The MFMAs ran with the weights as the A operand, so the accumulators are the TRANSPOSED tile: lane (col, h) holds
+  // voxel x = col of the four y-rows ms, and register r of acc[ms][ns] is output channel
+  //     ch(ns, r, h) = ns*32 + (r & 3) + 8*(r >> 2) + 4*h,
+  // i.e. four runs of 4 consecutive channels per lane: exactly what a channels-last store wants (8-B / 16-B pieces,
+  // the h = 0 / 1 lanes writing adjacent pieces), with no transposition through LDS and no workgroup barrier between
+  // the K loop and the stores.
   const int gz_w = STEP * (z0 + wave) + pz;
-  double s1[NSUB], s2[NSUB];
+  const int gx_l = STEP * (x0 + col) + px;
+  unsigned vlin[4];   // linear voxel index of this lane in y-row ms; 0xFFFFFFFF outside the volume
+  bool vok[4];
 #pragma unroll
-  for (int ns = 0; ns < NSUB; ++ns) {
-    s1[ns] = 0.0; s2[ns] = 0.0;
-    const int co = ntile * NCOL + ns * 32 + col;
-    const bool cvalid = co < a.cout;
-    const float bias = (a.bias != nullptr && cvalid) ? a.bias[co] : 0.f;
+  for (int ms = 0; ms < 4; ++ms) {
+    const int gy = STEP * (y0 + ms) + py;
+    vok[ms] = gz_w < a.D && gy < a.H && gx_l < a.W;
+    vlin[ms] = vok[ms] ? (unsigned)((gz_w * a.H + gy) * a.W + gx_l) : INVALID;
+  }
+  // (1) bias
+  if (a.bias != nullptr) {
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
-      const int gy = STEP * (y0 + ms) + py;
-      const bool rowok = a.stats != nullptr && cvalid && gz_w < a.D && gy < a.H;
-      // shifted sums: deviations from the row's first value are summed in f32 (no cancellation: they are of the
-      // order of the standard deviation), the shift is undone in f64
-      const float v0 = acc[ms][ns][0] + bias;
-      float p1 = 0.f, p2 = 0.f, cnt = 0.f;
+    for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int gx = STEP * (x0 + (r & 3) + 8 * (r >> 2) + 4 * h) + px;
-        const float val = acc[ms][ns][r] + bias;
-        acc[ms][ns][r] = val;
-        const bool ok = rowok && gx < a.W;
-        const float dv = ok ? val - v0 : 0.f;
-        p1 += dv;
-        p2 += dv * dv;
-        cnt += ok ? 1.f : 0.f;
+        const int co = ntile * NCOL + ns * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float bias = co < a.cout ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) acc[ms][ns][r] += bias;
       }
-      const double d0 = (double)v0, dp1 = (double)p1, dc = (double)cnt;
-      s1[ns] += dp1 + dc * d0;
-      s2[ns] += (double)p2 + 2.0 * d0 * dp1 + dc * d0 * d0;
+  }
+  // (2) InstanceNorm partial sums of this wave's 128 voxels (fixed order, hence deterministic).  Per channel the
+  //     deviations from one of its values (the wave's first voxel) are summed in f32 -- they are of the order of the
+  //     standard deviation, so nothing cancels -- and the shift is undone in f64.  The 32 per-lane values (16 sums,
+  //     16 sums of squares) are reduced over the 32 voxel lanes of each half-wave by a reduce-scatter on DPP:
+  //     5 steps of "keep half of my values, add the partner's copy of them", partners l^16, l^8, l^7, l^2, l^1
+  //     (ds_swizzle, row_ror:8, row_half_mirror, quad_perm), after which lane j of a half owns value j.
+  constexpr int K_BYTES = (IN_ITEMS + W_ITEMS) * 4096;     // the K-loop tiles; slower waves may still be reading them
+  constexpr int E_BYTES = 4 * 128 * (NCOL * (int)sizeof(T) + 16);   // the four waves' store stages (step 3)
+  double* red = reinterpret_cast<double*>(smem + (K_BYTES > E_BYTES ? K_BYTES : E_BYTES));   // [4 waves][NCOL][2]
+  if (a.stats != nullptr) {
+    float cntf = 0.f;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) cntf += vok[ms] ? 1.f : 0.f;
+    cntf += dpp_fetch<0xB1>(cntf); cntf += dpp_fetch<0x4E>(cntf); cntf += dpp_fetch<0x141>(cntf); cntf += dpp_fetch<0x140>(cntf);
+    cntf += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, cntf), 0x401F));   // xor 16
+    const int j = col, rj = j & 15;
+    // partial-sum type: f32 for bf16 activations (the stored tensor keeps 8 bits of mantissa anyway); f64 in the f32
+    // parity mode, whose gradients are ill-conditioned enough to see an f32 reduction tree
+    typedef typename std::conditional<sizeof(T) == 4, double, float>::type R;
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      float v0[16];
+      R val[32];   // val[0..15] sums, val[16..31] sums of squares
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // the shift: this channel's value at the half-wave's first lane, y-row 0 (any value of the channel will do)
+        v0[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane & 32) * 4, __builtin_bit_cast(int, acc[0][ns][r])));
+        R p1 = 0, p2 = 0;
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          const R dv = vok[ms] ? (R)acc[ms][ns][r] - (R)v0[r] : (R)0;   // (exact in the f64 mode)
+          p1 += dv;
+          p2 += dv * dv;
+        }
+        val[r] = p1; val[16 + r] = p2;
+      }
+      {  // reduce-scatter over the 32 lanes of each half
+        const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0, b0 = (j & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const R keep = b4 ? val[16 + i] : val[i], send = b4 ? val[i] : val[16 + i];
+          val[i] = keep + xlane_swz16(send);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const R keep = b3 ? val[8 + i] : val[i], send = b3 ? val[i] : val[8 + i];
+          val[i] = keep + xlane_dpp<0x128>(send);   // row_ror:8 == lane ^ 8
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const R keep = b2 ? val[4 + i] : val[i], send = b2 ? val[i] : val[4 + i];
+          val[i] = keep + xlane_dpp<0x141>(send);   // row_half_mirror == lane ^ 7
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const R keep = b1 ? val[2 + i] : val[i], send = b1 ? val[i] : val[2 + i];
+          val[i] = keep + xlane_dpp<0x4E>(send);    // quad_perm [2,3,0,1] == lane ^ 2
+        }
+        {
+          const R keep = b0 ? val[1] : val[0], send = b0 ? val[0] : val[1];
+          val[0] = keep + xlane_dpp<0xB1>(send);    // quad_perm [1,0,3,2] == lane ^ 1
+        }
+      }
+      // lane j now owns value j: sum (j < 16) or sum of squares (j >= 16) of channel register rj
+      float sh = v0[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) sh = (rj == r) ? v0[r] : sh;
+      const R mine = val[0];
+      const R s_of_q = xlane_swz16(mine);   // lane j ^ 16: the sum that belongs to this lane's sum of squares
+      const double d0 = (double)sh, dc = (double)cntf;
+      const double tot = j < 16 ? (double)mine + dc * d0
+                                : (double)mine + 2.0 * d0 * (double)s_of_q + dc * d0 * d0;
+      const int cl = ns * 32 + (rj & 3) + 8 * (rj >> 2) + 4 * h;
+      red[(wave * NCOL + cl) * 2 + (j >> 4)] = tot;
     }
   }
   STAMP(6);   // bias + statistics arithmetic
-  __syncthreads();   // all waves are done with the K-loop tiles; LDS is reused below
-  STAMP(7);   // barrier after the K loop
-  // (2) statistics: per-wave partials through LDS, fixed-order sum.  This happens BEFORE the stores: a
-  //     __syncthreads() also waits for vmcnt(0), i.e. a barrier after the stores would wait for HBM write latency.
-  constexpr int STG = 64 * NCOL * 4;                       // bytes of one wave's transpose stage (64 voxels x NCOL f32)
-  double* red = reinterpret_cast<double*>(smem + 4 * STG);  // [4 waves][NCOL][2]
-  if (a.stats != nullptr) {
+
+  // (3) stores.  Two paths, chosen per launch:
+  //  * narrow destinations (<= 16 channels, a.direct): straight from the accumulators.  A lane writes its runs of 4
+  //    channels as 8-B / 16-B pieces; the h = 0 / 1 lanes and neighbouring voxels together cover contiguous memory
+  //    (voxel pitch 16-32 B), so the stores coalesce and neither LDS nor a barrier is needed.  Destinations are reached
+  //    through buffer descriptors: 32-bit offsets, voxels outside the volume (offset 2^32 - ...) dropped by the range check.
+  //  * wide destinations: the same stores would be 8-B pieces one voxel pitch (>= 64 B) apart, nothing for the write
+  //    coalescer to merge (measured: 240 cycles per store instruction on 32-channel outputs).  So each wave restages
+  //    its 128 voxels through LDS -- cheaply, because the transposed accumulators already hold runs of 4 channels: one
+  //    ds_write_b64 / b128 per run into [voxel][NCOL channels] rows (row pitch +16 B: conflict-free) -- and stores whole
+  //    16-B pieces, 4-8 adjacent lanes covering one voxel's contiguous channels.
+  if (a.direct) {
+    const int daccmask = a.dacc0 | (a.dacc1 << 1) | (a.dacc2 << 2);
+    const int dC0 = a.dstC0, dC1 = a.dstC1, dC2 = a.dstC2;
+    const unsigned long long dp0 = reinterpret_cast<unsigned long long>(a.dst0), dp1 = reinterpret_cast<unsigned long long>(a.dst1),
+                             dp2 = reinterpret_cast<unsigned long long>(a.dst2);
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
-      const double u = s1[ns] + __shfl_xor(s1[ns], 32, 64);
-      const double v = s2[ns] + __shfl_xor(s2[ns], 32, 64);
-      if (h == 0) {
-        red[(wave * NCOL + ns * 32 + col) * 2] = u;
-        red[(wave * NCOL + ns * 32 + col) * 2 + 1] = v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co8 = ntile * NCOL + ns * 32 + 8 * q;
+        if (co8 >= a.cout) continue;
+        // which destination: by arithmetic, not select chains over the argument struct's fields -- those the compiler
+        // turns into a scratch lookup table whose reload waits (s_waitcnt vmcnt(0)) for every store issued so far
+        const int w1 = co8 >= a.dcum1 ? 1 : 0, w2 = co8 >= a.dcum2 ? 1 : 0;
+        const int dC = dC0 + w1 * (dC1 - dC0) + w2 * (dC2 - dC1);
+        const int cl = co8 - w1 * (a.dcum1 - w2 * a.dcum1) - w2 * a.dcum2;
+        const int dacc = (daccmask >> (w1 + w2)) & 1;
+        const unsigned long long dpu = dp0 + (unsigned long long)w1 * (dp1 - dp0) + (unsigned long long)w2 * (dp2 - dp1);
+        void* dpv = reinterpret_cast<void*>(dpu);
+        if (dpv == nullptr) continue;
+        T* dbase = reinterpret_cast<T*>(dpv) + (long long)n * V * dC + cl;
+        const long long davail = ((long long)V * dC - cl) * (long long)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(uniform_ptr(dbase)), 0, __builtin_amdgcn_readfirstlane((int)davail), 0x00020000);
+        const unsigned dstride = __builtin_amdgcn_readfirstlane((unsigned)(dC * (int)sizeof(T)));
+        const unsigned hofs = (unsigned)(4 * h * (int)sizeof(T));
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          const unsigned off = vok[ms] ? vlin[ms] * dstride + hofs : 0x80000000u;   // beyond any admitted sample: dropped
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[ms][ns][4 * q + i];
+          if constexpr (sizeof(T) == 2) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            if (dacc) {
+              const u32x2 o = __builtin_amdgcn_raw_buffer_load_b64(rd, off, 0, 0);
+              v[0] += bf16_bits_to_f32(o.x & 0xffffu); v[1] += bf16_bits_to_f32(o.x >> 16);
+              v[2] += bf16_bits_to_f32(o.y & 0xffffu); v[3] += bf16_bits_to_f32(o.y >> 16);
+            }
+            u32x2 u;
+            u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+            u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(u, rd, off, 0, 0);
+          } else {
+            if (dacc) {
+              const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rd, off, 0, 0);
+              v[0] += __uint_as_float(o.x); v[1] += __uint_as_float(o.y); v[2] += __uint_as_float(o.z); v[3] += __uint_as_float(o.w);
+            }
+            u32x4 u;
+            u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rd, off, 0, 0);
+          }
+        }
       }
     }
-    __syncthreads();
+    STAMP(10);   // store issue
+  } else {
+    __syncthreads();   // every wave has left the K loop: its tiles are dead, the stages below reuse that memory
+    STAMP(7);   // barrier after the K loop
+    constexpr int ROWB = NCOL * (int)sizeof(T) + 16;          // stage row pitch in bytes
+    constexpr int PIECES = NCOL * (int)sizeof(T) / 16;        // 16-B pieces per voxel
+    constexpr int CPP = 16 / (int)sizeof(T);                  // channels per piece
+    unsigned char* stage = smem + wave * (128 * ROWB);
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          unsigned char* sp = stage + (ms * 32 + col) * ROWB + (ns * 32 + 8 * q + 4 * h) * (int)sizeof(T);
+          if constexpr (sizeof(T) == 2) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 u;
+            u.x = f32_to_bf16_bits(acc[ms][ns][4 * q]) | (f32_to_bf16_bits(acc[ms][ns][4 * q + 1]) << 16);
+            u.y = f32_to_bf16_bits(acc[ms][ns][4 * q + 2]) | (f32_to_bf16_bits(acc[ms][ns][4 * q + 3]) << 16);
+            *reinterpret_cast<u32x2*>(sp) = u;
+          } else {
+            u32x4 u;
+            u.x = __float_as_uint(acc[ms][ns][4 * q]); u.y = __float_as_uint(acc[ms][ns][4 * q + 1]);
+            u.z = __float_as_uint(acc[ms][ns][4 * q + 2]); u.w = __float_as_uint(acc[ms][ns][4 * q + 3]);
+            *reinterpret_cast<u32x4*>(sp) = u;
+          }
+        }
+    __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order
+    STAMP(9);   // stage writes
+    {
+      // the lane's piece (hence destination tensor and channel offset) is the same for every item: item % PIECES == lane % PIECES
+      const int piece = lane % PIECES;
+      const int co0 = ntile * NCOL + piece * CPP;
+      T* sdst = nullptr; int sdC = 0, sdacc = 0;
+      if (co0 < a.cout) {
+        void* dpv = a.dst0; int cl = co0;
+        sdC = a.dstC0; sdacc = a.dacc0;
+        if (co0 >= a.dcum2) { dpv = a.dst2; sdC = a.dstC2; sdacc = a.dacc2; cl = co0 - a.dcum2; }
+        else if (co0 >= a.dcum1) { dpv = a.dst1; sdC = a.dstC1; sdacc = a.dacc1; cl = co0 - a.dcum1; }
+        if (dpv != nullptr) sdst = reinterpret_cast<T*>(dpv) + cl;
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * PIECES; ++i) {
+        const int item = lane + 64 * i;
+        const int vl = item / PIECES;                          // voxel of the wave's 4 x 32 block
+        const int gy = STEP * (y0 + (vl >> 5)) + py, gx = STEP * (x0 + (vl & 31)) + px;
+        if (sdst != nullptr && gz_w < a.D && gy < a.H && gx < a.W) {
+          u32x4 u = *reinterpret_cast<const u32x4*>(stage + vl * ROWB + piece * 16);
+          u32x4* qp = reinterpret_cast<u32x4*>(sdst + ((long long)n * V + ((long long)gz_w * a.H + gy) * a.W + gx) * sdC);
+          if (sdacc) {
+            const u32x4 o = *qp;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float lo = bf16_bits_to_f32(u[e] & 0xffffu) + bf16_bits_to_f32(o[e] & 0xffffu);
+                const float hi = bf16_bits_to_f32(u[e] >> 16) + bf16_bits_to_f32(o[e] >> 16);
+                u[e] = f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[e] = __float_as_uint(__uint_as_float(u[e]) + __uint_as_float(o[e]));
+            }
+          }
+          *qp = u;
+        }
+      }
+    }
+    STAMP(10);   // stage reads + store issue
+
+  }
+  // (4) cross-wave statistics: one barrier that waits for the LDS writes only (a __syncthreads() would also wait for
+  //     the global stores above to be acknowledged), then a fixed-order sum of the four wave partials
+  if (a.stats != nullptr) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (tid < NCOL * 2) {
       const int c = tid >> 1, k = tid & 1;
       const int co = ntile * NCOL + c;
@@ -344,53 +544,6 @@ conv_igemm_kernel(ConvKArgs a) {
         a.stats[(((long long)n * gridDim.x + tile_slot) * a.cout + co) * 2 + k] = tot;
       }
     }
-  }
-  STAMP(9);   // cross-wave statistics
-  // (3) wave-private transpose (no workgroup barrier): two passes of 2 x-rows (64 voxels) through this wave's own
-  //     LDS stage, then every lane stores 8 channels (16/32 B) of one voxel
-  // store-phase destination of this lane (its 8-channel group is the same for every item): selected once
-  // (after the K loop, so it costs no registers there) so that no select chain / lookup table -- which the compiler
-  // would place in scratch and reload behind s_waitcnt vmcnt(0) -- sits between the global stores
-  constexpr int GRP = NCOL / 8;
-  T* sdst = nullptr; int sdC = 0, sdacc = 0;
-  {
-    const int co0 = ntile * NCOL + (lane % GRP) * 8;
-    if (co0 < a.cout) {
-      void* dpv = a.dst0; int cl = co0;
-      sdC = a.dstC0; sdacc = a.dacc0;
-      if (co0 >= a.dcum2) { dpv = a.dst2; sdC = a.dstC2; sdacc = a.dacc2; cl = co0 - a.dcum2; }
-      else if (co0 >= a.dcum1) { dpv = a.dst1; sdC = a.dstC1; sdacc = a.dacc1; cl = co0 - a.dcum1; }
-      if (dpv != nullptr) sdst = reinterpret_cast<T*>(dpv) + cl;
-    }
-  }
-
-  float* stage = reinterpret_cast<float*>(smem + wave * STG);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns)
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int xl = (r & 3) + 8 * (r >> 2) + 4 * h;
-          stage[(m2 * 32 + xl) * NCOL + ns * 32 + col] = acc[pass * 2 + m2][ns][r];
-        }
-    __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order
-    STAMP(10);   // transpose: stage writes
-#pragma unroll
-    for (int i = 0; i < GRP; ++i) {
-      const int item = lane + 64 * i;            // 64 voxels x GRP groups; item % GRP == lane % GRP
-      const int vl = item / GRP, grp = item % GRP;
-      const int gy = STEP * (y0 + pass * 2 + (vl >> 5)) + py, gx = STEP * (x0 + (vl & 31)) + px;
-      if (sdst != nullptr && gz_w < a.D && gy < a.H && gx < a.W) {
-        float v[8];
-        load8(stage + vl * NCOL + grp * 8, v);
-        T* q = sdst + ((long long)n * V + ((long long)gz_w * a.H + gy) * a.W + gx) * sdC;
-        store_vec8(q, v, sdacc);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
   }
 #ifdef SEUNET_STAMP
   STAMP(11);   // transpose: stage reads + global stores
@@ -476,8 +629,8 @@ static int launch_one(const ConvKArgs& a, dim3 grid, hipStream_t s) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int NVH = (CV_TZ + 2 * HALO) * (CV_TY + 2 * HALO) * (CV_TX + 2 * HALO);
   constexpr int LDS_K = ((NVH * 2 + 255) / 256 + (TAPS * 64 * NSUB + 255) / 256) * 4096;   // K-loop tiles, padded to whole staging rounds
-  constexpr int LDS_E = 4 * 64 * 32 * NSUB * 4 + 4 * 32 * NSUB * 16;   // 4 wave-private transpose stages + stats partials
-  constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
+  constexpr int LDS_E = 4 * 128 * (32 * NSUB * (int)sizeof(T) + 16);                       // the four waves' store stages
+  constexpr int LDS = (LDS_K > LDS_E ? LDS_K : LDS_E) + 4 * 32 * NSUB * 16;                // + the statistics partials
   static bool configured = false;  // per instantiation
   if (!configured) {
     SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, NSUB, TAPS, DIL>),
@@ -530,6 +683,8 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   const int st = taps == 27 ? dil : 1;
   a.tx = cdiv(cdiv(d.W, st), CV_TX); a.ty = cdiv(cdiv(d.H, st), CV_TY); a.tz = cdiv(cdiv(d.D, st), CV_TZ);
   a.nchunks = cdiv(a.cin, conv_kc(dtype));
+  a.direct = 1;
+  for (int i = 0; i < dst.n; ++i) if (dst.C[i] > 16) a.direct = 0;
   a.debug = g_conv_debug;
   const int ncol = conv_ncol(a.cin, a.cout);
   dim3 grid(a.tx * a.ty * a.tz * st * st * st, cdiv(a.cout, ncol), d.N);
@@ -539,6 +694,10 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
     SEUNET_CHECK((long long)d.vox() * src.C[i] * (long long)dtype_size(dtype) < (1LL << 31),
                  "conv: one sample of source %d is %lld bytes; the MFMA path addresses < 2^31 bytes per sample "
                  "(tile the volume, e.g. sliding_window_predict)", i, (long long)d.vox() * src.C[i] * (long long)dtype_size(dtype));
+  for (int i = 0; i < dst.n; ++i)
+    SEUNET_CHECK((long long)d.vox() * dst.C[i] * (long long)dtype_size(dtype) < (1LL << 31),
+                 "conv: one sample of destination %d is %lld bytes; the MFMA path addresses < 2^31 bytes per sample",
+                 i, (long long)d.vox() * dst.C[i] * (long long)dtype_size(dtype));
   if (dtype == SEUNET_BF16) return launch_t<bf16_t>(taps, dil, ncol / 32, a, grid, s);
   return launch_t<float>(taps, dil, ncol / 32, a, grid, s);
 }

@@ -117,7 +117,10 @@ def test_conv1x1x1_forward(S, dtype, impl, split, cout):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("impl", IMPL)
 @pytest.mark.parametrize("case", [([32, 32], 32, 1, 27), ([16], 32, 2, 27), ([64, 64], 64, 1, 27),
-                                  ([32, 8, 16], 32, 1, 1), ([32, 64], 32, 1, 1)])
+                                  ([32, 8, 16], 32, 1, 1), ([32, 64], 32, 1, 1),
+                                  # narrow destinations only: the store path that goes straight from the accumulators
+                                  ([8], 16, 1, 27), ([16], 32, 2, 27), ([8, 16], 32, 1, 27), ([16, 8, 8], 64, 1, 27),
+                                  ([8], 32, 1, 1), ([16, 16], 16, 1, 1)])
 def test_conv_data_gradient(S, dtype, impl, case):
     """dgrad = same kernel on flipped/transposed weights, split over the concatenated inputs, with +=."""
     split, cout, dil, taps = case
