@@ -65,6 +65,13 @@ for name, split, cout, dil, size in CASES:
             used = rec.sum(1) > 0
             v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
             print("  stamps %s %s: " % (name, nm) + "  ".join("%s %.1f%%" % (names[i], 100 * float(v[i]) / tot) for i in range(12)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
+        if "wgrad" in which:
+            wn = ["prologue", "barrier1", "dma-issue", "dma-land+barrier2", "mfma-rows", "slab-store"]
+            wgrad(); torch.cuda.synchronize(); dbg.zero_(); wgrad(); torch.cuda.synchronize()
+            rec = dbg.view(-1, 12).double()
+            used = rec.sum(1) > 0
+            v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
+            print("  stamps %s wgrad: " % name + "  ".join("%s %.1f%%" % (wn[i], 100 * float(v[i]) / tot) for i in range(6)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
     res = []
     for nm, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
         if nm in which:

@@ -14,8 +14,11 @@
 //   output      each workgroup stores its accumulators once to a slab; a second kernel sums the slabs in a
 //               fixed order (deterministic, no atomics) straight into the PyTorch (Cout,Cin,3,3,3) layout
 #include "seunet_common.h"
+#include <utility>
 
 namespace seunet {
+
+extern unsigned long long* g_conv_debug;   // conv_igemm.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
@@ -32,6 +35,7 @@ struct WgArgs {
   int N, D, H, W;
   int tx, ty, tz;          // tile counts per sample
   int co_tiles;
+  unsigned long long* debug;   // diagnostic builds only (-DSEUNET_STAMP)
 };
 
 // spatial tile (z, y; x is always 32) on the (sub-)lattice.  Dilation 2 runs on the 8 parity sub-lattices
@@ -52,9 +56,19 @@ __device__ __forceinline__ const void* wg_uniform_ptr(const void* p) {
 // [16-byte piece of the 32 channels][voxel][16 B]: one DMA wave-instruction writes 1 KB contiguous (64 consecutive
 // voxels of one piece, the piece -- hence the source tensor -- being wave-uniform); plane strides are = 64 (mod 256)
 // bytes so the transposing reads (4 voxels x 4 pieces per 32 lanes) touch every LDS bank once.
+#ifdef SEUNET_STAMP
+#define WSTAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); ph[i] += _t - t_last; t_last = _t; } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
+
 template <typename T, int TAPS, int DIL, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 4)   // two workgroups per CU
 wgrad_kernel(WgArgs a) {
+#ifdef SEUNET_STAMP
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int STEP = (TAPS == 27) ? DIL : 1;
   constexpr int TZ = WgTile<T>::TZ, TY = WgTile<T>::TY, TX = 32;
@@ -94,9 +108,72 @@ wgrad_kernel(WgArgs a) {
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+  // bf16 operand addressing.  lane -> 8-byte chunk of a 16-voxel x 32-channel operand: 16-lane group grp covers channels
+  // 16*(grp&1).. and voxels 8*(grp>>1)..+3 (second read: +4 voxels = +64 B); lane li supplies voxel li>>2, channels 4*(li&3)..+3
+  const unsigned char* abase[NT];   // X image: lane offset + this wave's tap ti (1x1x1: + this wave's first row)
+  const unsigned char* bbase;       // dY image
+  {
+    const int grp = lane >> 4, li = lane & 15;
+    const int pl = 2 * (grp & 1) + ((li & 3) >> 1);                       // 16-byte piece (plane)
+    const int vo = 8 * (grp >> 1) + (li >> 2);                            // voxel within the 16-voxel step
+    const int sub = (li & 1) * 8;                                         // byte offset inside the piece
+    const int wrow = (TAPS == 27) ? 0 : wave;                             // 1x1x1: wave w takes rows w, w + NW, ...
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+      abase[ti] = xs + (PPV == 4 ? pl : 0) * XPL + ((wrow / TY * HY + wrow % TY) * HX + tapoff[ti] + vo) * 16 + sub;
+    bbase = ys + (PPV == 4 ? pl : 0) * YPL + (wrow * TX + vo) * 16 + sub;
+  }
 
-  // issue the DMA of one tile: wave-instruction index wi = wave + NW*k covers piece wi % PPV of voxel group wi / PPV
-  auto stage = [&](int tile) {
+  // ---- DMA plan.  Wave-instruction k of a wave covers piece (wave + NW*(k % PV)) of voxel group k / PV (PV = PPV/NW
+  // pieces per wave), 64 consecutive voxels of the LDS image per instruction.  Everything that does not depend on the
+  // tile is computed once per workgroup: the lane's halo coordinates of each voxel group (one packed register per
+  // group) and, per piece of this wave, the source tensor / channel (scalars).  Per tile and instruction that leaves a
+  // range test of the three coordinates, one 64-bit multiply-add and the zero-page select: ~16 vector instructions
+  // where recomputing the plan from scratch took ~50 -- the DMA issue phase was as long as the MFMA phase (stamps).
+  static_assert(PPV % NW == 0, "pieces per voxel must be a multiple of the wave count");
+  constexpr int PV = PPV / NW;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  // the lane's halo coordinates of its XG voxel groups, 16 bits each (hz: bits 0-1, hy: 2-4, hx: 5-10, bit 15: beyond the
+  // halo tile), parked in a thread-private 32-byte LDS slot and re-read per tile: kept in registers they stay live
+  // across the MFMA phase, and the spills that follow reload through scratch behind s_waitcnt vmcnt(0) -- i.e. behind
+  // every DMA already in flight
+  static_assert(XG <= 16 && HZ <= 4 && HY <= 8 && HX <= 64, "packed halo coordinates");
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4* cslot = reinterpret_cast<u32x4*>(smem + PPV * (XPL + YPL) + tid * 32);
+  {
+    unsigned w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < XG; ++g) {
+      const int vox = g * 64 + lane;
+      const int hx = vox % HX, r2 = vox / HX;
+      const int hy = r2 % HY, hz = r2 / HY;
+      const unsigned c = vox < NVH ? ((unsigned)hz | ((unsigned)hy << 2) | ((unsigned)hx << 5)) : 0x8000u;
+      w[g >> 1] |= c << (16 * (g & 1));
+    }
+    u32x4 lo, hi;
+    lo.x = w[0]; lo.y = w[1]; lo.z = w[2]; lo.w = w[3]; hi.x = w[4]; hi.y = w[5]; hi.z = w[6]; hi.w = w[7];
+    cslot[0] = lo; cslot[1] = hi;
+  }
+  const unsigned char* xbase[PV]; long long xstride[PV]; bool xvalid[PV];   // per piece of this wave (scalars)
+  const unsigned char* ybase[PV]; bool yvalid[PV];
+#pragma unroll
+  for (int j = 0; j < PV; ++j) {
+    const int piece = wave_s + NW * j;
+    const int ch0 = ci0 + piece * EPP;
+    const void* sp = a.src0; int sC = a.srcC0, c = ch0;
+    if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
+    else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
+    xvalid[j] = ch0 < a.cin;
+    xbase[j] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(sp) + c);
+    xstride[j] = (long long)sC * (long long)sizeof(T);
+    const int cy0 = co0 + piece * EPP;
+    yvalid[j] = cy0 < a.cout;
+    ybase[j] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(a.dy) + cy0);
+  }
+  const long long ystride = (long long)a.cout * (long long)sizeof(T);
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero);
+
+  auto stage = [&](int tile) __attribute__((always_inline)) {
     const int n = tile / tiles_per_sample;
     int t = tile % tiles_per_sample;
     const int par = t / tiles_per_par; t %= tiles_per_par;
@@ -105,77 +182,118 @@ wgrad_kernel(WgArgs a) {
     const int bz = t / a.ty;
     const int px = par % STEP, py = (par / STEP) % STEP, pz = par / (STEP * STEP);
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
-#pragma unroll 1   // keep the index arithmetic out of registers: it is recomputed per DMA instruction
+    // halo coordinate h is inside the volume iff lo <= h <= hi (scalars): lattice index l = origin - HALO + h needs
+    // l >= 0 and STEP*l + parity < dim, i.e. l <= floor((dim - 1 - parity) / STEP)  (= (dim - 1 - parity + STEP) / STEP - 1)
+    const int zlo = z0 >= HALO ? 0 : HALO - z0, ylo = y0 >= HALO ? 0 : HALO - y0, xlo = x0 >= HALO ? 0 : HALO - x0;
+    const int zmax = (a.D - 1 - pz + STEP) / STEP - 1, ymax = (a.H - 1 - py + STEP) / STEP - 1, xmax = (a.W - 1 - px + STEP) / STEP - 1;
+    int zsp = zmax - (z0 - HALO) - zlo, ysp = ymax - (y0 - HALO) - ylo, xsp = xmax - (x0 - HALO) - xlo;   // hi - lo
+    const bool any = zsp >= 0 && ysp >= 0 && xsp >= 0;
+    if (!any) zsp = ysp = xsp = 0;
+    // voxel index of halo coordinate (0,0,0); negative on the low borders (those lanes are masked before any access)
+    const long long origin = ((long long)(STEP * (z0 - HALO) + pz) * a.H + (STEP * (y0 - HALO) + py)) * a.W + (STEP * (x0 - HALO) + px);
+    const long long nofs = (long long)n * V;
+    const u32x4 clo = cslot[0], chi = cslot[1];
+    const unsigned cw[8] = {clo.x, clo.y, clo.z, clo.w, chi.x, chi.y, chi.z, chi.w};
+#pragma unroll
     for (int k = 0; k < X_ITEMS; ++k) {
-      const int wi = wave + NW * k;
-      if (wi < XG * PPV) {                          // wave-uniform
-        const int piece = wi % PPV, vg = wi / PPV, vox = vg * 64 + lane;
-        const int hx = vox % HX;
-        const int r2 = vox / HX;
-        const int hy = r2 % HY, hz = r2 / HY;
-        const int lz = z0 - HALO + hz, ly = y0 - HALO + hy, lx = x0 - HALO + hx;
-        const int gz = STEP * lz + pz, gy = STEP * ly + py, gx = STEP * lx + px;
-        const int ch0 = ci0 + piece * EPP;
-        const bool ok = vox < NVH && lz >= 0 && ly >= 0 && lx >= 0 && gz < a.D && gy < a.H && gx < a.W && ch0 < a.cin;
-        const void* sp = a.src0; int sC = a.srcC0, c = ch0;
-        if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
-        else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
-        const T* g = ok ? reinterpret_cast<const T*>(sp) + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * sC + c
-                        : reinterpret_cast<const T*>(a.zero);
-        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(xs + piece * XPL + vg * 1024), 16, 0, 0);
+      const int j = k % PV, g = k / PV;
+      if (g < XG) {
+        const unsigned c = cw[g >> 1] >> (16 * (g & 1));
+        const unsigned cz = c & 3u, cy = (c >> 2) & 7u, cx = (c >> 5) & 63u;
+        const bool ok = (int)(any & xvalid[j]) & (int)((c & 0x8000u) == 0) & (int)((cz - (unsigned)zlo) <= (unsigned)zsp) &
+                        (int)((cy - (unsigned)ylo) <= (unsigned)ysp) & (int)((cx - (unsigned)xlo) <= (unsigned)xsp);
+        const unsigned rel = (unsigned)STEP * ((cz * (unsigned)a.H + cy) * (unsigned)a.W + cx);
+        const unsigned char* sb = xbase[j] + (nofs + origin) * xstride[j];   // scalar
+        const unsigned char* gp = sb + (unsigned long long)rel * (unsigned long long)(unsigned)xstride[j];
+        gp = ok ? gp : zero_page;
+        __builtin_amdgcn_global_load_lds((glb_void*)gp, (lds_void*)(xs + (wave_s + NW * j) * XPL + g * 1024), 16, 0, 0);
       }
     }
-#pragma unroll 1
+    // dY tile: voxel (group * 64 + lane) -> (lz, ly, lx) by shifts (TX = 32, TY = 4)
+    const long long yorigin = ((long long)(STEP * z0 + pz) * a.H + (STEP * y0 + py)) * a.W + (STEP * x0 + px);
+    const int yzsp = zmax - z0, yysp = ymax - y0, yxsp = xmax - x0;
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));   // per-tile copy: keeps the (tile-invariant) offsets below from being hoisted and spilled
+#pragma unroll
     for (int k = 0; k < Y_ITEMS; ++k) {
-      const int wi = wave + NW * k;
-      if (wi < YG * PPV) {
-        const int piece = wi % PPV, vg = wi / PPV, vox = vg * 64 + lane;
-        const int lx = vox % TX;
-        const int r2 = vox / TX;
+      const int j = k % PV, g = k / PV;
+      if (g < YG) {
+        const int vox = g * 64 + lane_t;
+        const int lx = vox % TX, r2 = vox / TX;
         const int ly = r2 % TY, lz = r2 / TY;
-        const int gz = STEP * (z0 + lz) + pz, gy = STEP * (y0 + ly) + py, gx = STEP * (x0 + lx) + px;
-        const int ch0 = co0 + piece * EPP;
-        const bool ok = vox < NVT && gz < a.D && gy < a.H && gx < a.W && ch0 < a.cout;
-        const T* g = ok ? reinterpret_cast<const T*>(a.dy) + ((long long)n * V + ((long long)gz * a.H + gy) * a.W + gx) * a.cout + ch0
-                        : reinterpret_cast<const T*>(a.zero);
-        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(ys + piece * YPL + vg * 1024), 16, 0, 0);
+        const bool ok = (int)yvalid[j] & (int)(vox < NVT) & (int)(lz <= yzsp) & (int)(ly <= yysp) & (int)(lx <= yxsp);
+        const unsigned rel = (unsigned)STEP * (unsigned)((lz * a.H + ly) * a.W + lx);
+        const unsigned char* sb = ybase[j] + (nofs + yorigin) * ystride;     // scalar
+        const unsigned char* gp = sb + (unsigned long long)rel * (unsigned long long)(unsigned)ystride;
+        gp = ok ? gp : zero_page;
+        __builtin_amdgcn_global_load_lds((glb_void*)gp, (lds_void*)(ys + (wave_s + NW * j) * YPL + g * 1024), 16, 0, 0);
       }
     }
   };
 
+  WSTAMP(0);   // prologue
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     __syncthreads();   // previous tile's reads are done
+    WSTAMP(1);   // barrier 1
     stage(tile);
+    WSTAMP(2);   // DMA issue
     __syncthreads();   // (waits vmcnt(0): the DMA of every wave has landed)
-    for (int row = 0; row < TZ * TY; ++row) {
-      if (TAPS == 1 && (row % NW) != wave) continue;   // 1x1x1: rows are split over the waves
-      const int lz = row / TY, ly = row % TY;
-      const int xrow = (lz * HY + ly) * HX;             // tap (0,0,0) voxel index of this row in the halo tile
-      const int yrow = row * TX;
-      if constexpr (sizeof(T) == 2) {
-        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-        // lane -> 8-byte chunk of a 16-voxel x 32-channel operand: 16-lane group grp covers channels 16*(grp&1).. and
-        // voxels 8*(grp>>1)..+3 (second read: +4); lane li supplies voxel li>>2, channels 4*(li&3)..+3
-        const int grp = lane >> 4, li = lane & 15;
-        const int pl = 2 * (grp & 1) + ((li & 3) >> 1);                       // 16-byte piece (plane)
-        const int vo = 8 * (grp >> 1) + (li >> 2);                            // voxel within the 16-voxel step
-        const int sub = (li & 1) * 8;                                         // byte offset inside the piece
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const unsigned char* yb = ys + pl * YPL + (yrow + kk * 16 + vo) * 16 + sub;
-          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)yb);
-          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(yb + 64));
-          const bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-          for (int ti = 0; ti < NT; ++ti) {
-            const unsigned char* xa = xs + pl * XPL + (xrow + tapoff[ti] + kk * 16 + vo) * 16 + sub;
-            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)xa);
-            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(xa + 64));
-            const bf16x8 afr = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
-          }
+    WSTAMP(3);   // DMA landing + barrier 2
+    if constexpr (sizeof(T) == 2) {
+      // MFMA phase, software-pipelined by hand.  One step = one MFMA = (row, 16-voxel K-step kk, tap ti).  Left to the
+      // compiler this became read -> s_waitcnt lgkmcnt(0) -> MFMA per step on one set of fragment registers (every MFMA
+      // behind a full LDS latency: the phase ran at half speed) plus a separate address register per step.  Here the A
+      // fragments of step s + 2 and the B fragments of the next (row, kk) are requested before the MFMA of step s
+      // issues (rotating buffers, compile-time indices), and a step's address is "per-tap base register + immediate".
+      typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+      constexpr int ROWS = (TAPS == 27) ? TZ * TY : TZ * TY / NW;    // 1x1x1: the rows are split over the waves
+      constexpr int NRK = ROWS * 2, NSTEP = NRK * NT;
+      auto a_off = [](int rk) constexpr {   // byte offset of (row, kk) inside the X image, relative to the tap base
+        const int ri = rk >> 1, kk = rk & 1;
+        const int row = (TAPS == 27) ? ri : ri * NW;                 // (1x1x1: + wave, folded into the base)
+        return ((row / TY * HY + row % TY) * HX + kk * 16) * 16;
+      };
+      auto b_off = [](int rk) constexpr {
+        const int ri = rk >> 1, kk = rk & 1;
+        const int row = (TAPS == 27) ? ri : ri * NW;
+        return (row * TX + kk * 16) * 16;
+      };
+      bf16x4 abuf[3][2], bbuf[2][2];
+      auto load_a = [&](auto step_c) __attribute__((always_inline)) {
+        constexpr int st = decltype(step_c)::value;
+        if constexpr (st < NSTEP) {
+          constexpr int ti = st % NT, rk = st / NT;
+          abuf[st % 3][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(abase[ti] + a_off(rk)));
+          abuf[st % 3][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(abase[ti] + a_off(rk) + 64));
         }
-      } else {
+      };
+      auto load_b = [&](auto rk_c) __attribute__((always_inline)) {
+        constexpr int rk = decltype(rk_c)::value;
+        if constexpr (rk < NRK) {
+          bbuf[rk % 2][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(bbase + b_off(rk)));
+          bbuf[rk % 2][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(bbase + b_off(rk) + 64));
+        }
+      };
+      load_b(std::integral_constant<int, 0>{});
+      load_a(std::integral_constant<int, 0>{});
+      load_a(std::integral_constant<int, 1>{});
+      [&]<int... ST>(std::integer_sequence<int, ST...>) __attribute__((always_inline)) {
+        ([&]() __attribute__((always_inline)) {
+          constexpr int ti = ST % NT, rk = ST / NT;
+          load_a(std::integral_constant<int, ST + 2>{});
+          if constexpr (ti == 0) load_b(std::integral_constant<int, rk + 1>{});
+          const bf16x8 afr = __builtin_shufflevector(abuf[ST % 3][0], abuf[ST % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 bfr = __builtin_shufflevector(bbuf[rk % 2][0], bbuf[rk % 2][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);   // keep the issue order written here
+        }(), ...);
+      }(std::make_integer_sequence<int, NSTEP>{});
+    } else {
+      for (int row = 0; row < TZ * TY; ++row) {
+        if (TAPS == 1 && (row % NW) != wave) continue;   // 1x1x1: rows are split over the waves
+        const int lz = row / TY, ly = row % TY;
+        const int xrow = (lz * HY + ly) * HX;             // tap (0,0,0) voxel index of this row in the halo tile
+        const int yrow = row * TX;
         const int pl = col >> 2, sub = (col & 3) * 4;   // f32: channel col lives in plane col/4
 #pragma unroll 4
         for (int kk = 0; kk < 16; ++kk) {
@@ -189,6 +307,7 @@ wgrad_kernel(WgArgs a) {
         }
       }
     }
+    WSTAMP(4);   // MFMA rows of this tile
   }
   // ---- store this workgroup's accumulators: slab[(combo*G + wg) (x4 waves for 1x1)][tap][ci][co] ----
   if (TAPS == 27) {
@@ -212,6 +331,14 @@ wgrad_kernel(WgArgs a) {
       out[row * 32 + col] = acc[0][r];
     }
   }
+#ifdef SEUNET_STAMP
+  WSTAMP(5);   // slab store
+  if (a.debug != nullptr && lane == 0) {
+    const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave;
+    for (int i = 0; i < 6; ++i) a.debug[w * 12 + i] = ph[i];
+    for (int i = 6; i < 12; ++i) a.debug[w * 12 + i] = 0;
+  }
+#endif
 }
 
 // dW (PyTorch layout) = fixed-order sum of the slabs.  One thread per slab element (tap, ci, co) so that the
@@ -260,7 +387,7 @@ static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
   constexpr int TZ = WgTile<T>::TZ, TY = WgTile<T>::TY;
   constexpr int PPV = 32 / (16 / (int)sizeof(T));
   constexpr int NVH = (TZ + 2 * HALO) * (TY + 2 * HALO) * (32 + 2 * HALO), NVT = TZ * TY * 32;
-  constexpr int LDS = PPV * ((((NVH + 63) / 64) * 64 + 4) + (((NVT + 63) / 64) * 64 + 4)) * 16;
+  constexpr int LDS = PPV * ((((NVH + 63) / 64) * 64 + 4) + (((NVT + 63) / 64) * 64 + 4)) * 16 + NW * 64 * 32;   // + packed halo coordinates
   static bool configured = false;
   if (!configured) {
     SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL, NW>),
@@ -298,6 +425,7 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   const int st = taps == 27 ? dil : 1;
   a.tx = cdiv(cdiv(d.W, st), 32); a.ty = cdiv(cdiv(d.H, st), ty); a.tz = cdiv(cdiv(d.D, st), tz);
   a.co_tiles = cdiv(cout, 32);
+  a.debug = g_conv_debug;
   const int combos = cdiv(cin_logical, 32) * a.co_tiles;
   const int G = wgrad_groups(taps, combos, a.tx * a.ty * a.tz * st * st * st * d.N);
   dim3 grid(G, combos);
