@@ -11,16 +11,22 @@ only = sys.argv[1] if len(sys.argv) > 1 else ""
 reps = int(os.environ.get("REPS", 5))
 # name, splits, cout, dil, size
 CASES = [("dc5", [32, 32], 32, 1, 128), ("dc3", [64, 64], 64, 1, 64), ("ec3", [16], 32, 2, 128), ("dc6", [32], 16, 1, 128),
-         ("ec2", [8], 16, 1, 128), ("ec6", [32], 64, 2, 64), ("dc4", [64], 32, 1, 64)]
+         ("ec2", [8], 16, 1, 128), ("ec6", [32], 64, 2, 64), ("dc4", [64], 32, 1, 64),
+         # 1x1x1 layers (name ends in "_1"): the x33 / ec33 shortcut convolutions
+         ("x33_1", [8], 32, 1, 128), ("ec33_1", [32], 32, 1, 128), ("ec63_1", [64], 64, 1, 64)]
 dt = torch.bfloat16
 for name, split, cout, dil, size in CASES:
     if only and only != name:
         continue
+    if not only and name.endswith("_1") and not os.environ.get("ONE"):
+        continue
+    K = 1 if name.endswith("_1") else 3
+    TAPS = K ** 3
     cin = sum(split)
     srcs = [torch.randn((B, size, size, size, c), device="cuda", dtype=dt) for c in split]
-    w = torch.randn((cout, cin, 3, 3, 3), device="cuda") * 0.05
+    w = torch.randn((cout, cin, K, K, K), device="cuda") * 0.05
     dy = torch.randn((B, size, size, size, cout), device="cuda", dtype=dt)
-    flops = 2.0 * 27 * cin * cout * B * size ** 3
+    flops = 2.0 * TAPS * cin * cout * B * size ** 3
     def timeit(fn):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,20 +41,20 @@ for name, split, cout, dil, size in CASES:
     wpd = S.pack_weights(w, code, True)
     dims = _lib.Dims(B, size, size, size)
     out = torch.empty((B, size, size, size, cout), device="cuda", dtype=dt)
-    slots = lib.seunet_conv_stats_slots(0, 27, dil, dims)
+    slots = lib.seunet_conv_stats_slots(0, TAPS, dil, dims)
     stats = torch.zeros((B, slots, cout, 2), dtype=torch.float64, device="cuda")
     def fwd():
-        _lib.check(lib.seunet_conv3d_fwd(code, 0, 27, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, wp.data_ptr(), 0,
+        _lib.check(lib.seunet_conv3d_fwd(code, 0, TAPS, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, wp.data_ptr(), 0,
                                          None, 1, _lib.ptr_array([out]), _lib.int_array([cout]), _lib.int_array([0]), stats.data_ptr(), dims, _lib.stream_ptr()))
     gs = [torch.empty_like(s) for s in srcs]
     def dgrad():
-        _lib.check(lib.seunet_conv3d_fwd(code, 0, 27, dil, 1, _lib.ptr_array([dy]), _lib.int_array([cout]), cout, wpd.data_ptr(), 1,
+        _lib.check(lib.seunet_conv3d_fwd(code, 0, TAPS, dil, 1, _lib.ptr_array([dy]), _lib.int_array([cout]), cout, wpd.data_ptr(), 1,
                                          None, len(gs), _lib.ptr_array(gs), _lib.int_array(split), _lib.int_array([0] * len(gs)), None, dims, _lib.stream_ptr()))
-    nb = lib.seunet_conv3d_wgrad_workspace_bytes(27, cin, cout)
+    nb = lib.seunet_conv3d_wgrad_workspace_bytes(TAPS, cin, cout)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    dw = torch.empty((cout, cin, 3, 3, 3), device="cuda")
+    dw = torch.empty((cout, cin, K, K, K), device="cuda")
     def wgrad():
-        _lib.check(lib.seunet_conv3d_wgrad(code, 0, 27, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, dy.data_ptr(), cout,
+        _lib.check(lib.seunet_conv3d_wgrad(code, 0, TAPS, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, dy.data_ptr(), cout,
                                            dw.data_ptr(), ws.data_ptr(), nb, dims, _lib.stream_ptr()))
     which = os.environ.get("WHICH", "fwd,dgrad,wgrad").split(",")
     if os.environ.get("SEUNET_STAMP"):
