@@ -144,7 +144,14 @@ conv_igemm_kernel(ConvKArgs a) {
     vofs[k] = ok ? (unsigned)((gz * a.H + gy) * a.W + gx) : INVALID;
   }
   STAMP(8);   // index plan
-  const int lds_in0 = lane * 32 + (wave >> 1) * 2048 + 16 * (piece ^ ((lane >> 3) & 1));   // + k * 4096
+  // LDS image of the halo tile: planar, [16-B piece of the 32-B chunk][voxel][16 B] -- a staging instruction writes 1 KB
+  // contiguous, an MFMA fragment read (32 consecutive voxels of one piece) is 512 B contiguous: both conflict-free with
+  // no swizzle, so every fragment address is "lane base + compile-time offset" (the offset field of ds_read)
+  constexpr int PLANE = IN_ITEMS * 2048;
+  const int lds_in0 = piece * PLANE + ((wave >> 1) * 64 + lane) * 16;   // + k * 2048
+  // fragment bases of this lane: voxel (z-slice of the wave, x = col), k-half h
+  const unsigned char* afrag0 = in_tile + (sizeof(T) == 2 ? h * PLANE : 4 * h) + (wave * HY * HX + col) * 16;
+  const unsigned char* wfrag0 = w_tile + (h * NCOL + col) * (sizeof(T) == 2 ? 16 : 4);
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpack) +
                                (size_t)ntile * a.nchunks * (size_t)(W_TOTAL * 16);
   u32x4 rin[IN_ITEMS], rw[W_ITEMS];
@@ -212,7 +219,7 @@ conv_igemm_kernel(ConvKArgs a) {
     __syncthreads();   // every wave is done reading the previous chunk's tiles
     STAMP(1);   // barrier 1
 #pragma unroll
-    for (int k = 0; k < IN_ITEMS; ++k) *reinterpret_cast<u32x4*>(in_tile + lds_in0 + k * 4096) = rin[k];
+    for (int k = 0; k < IN_ITEMS; ++k) *reinterpret_cast<u32x4*>(in_tile + lds_in0 + k * 2048) = rin[k];
 #pragma unroll
     for (int k = 0; k < W_ITEMS; ++k) *reinterpret_cast<u32x4*>(w_tile + (tid + 256 * k) * 16) = rw[k];
     STAMP(2);   // wait for the fetched registers + LDS writes
@@ -234,56 +241,60 @@ conv_igemm_kernel(ConvKArgs a) {
     }
     STAMP(4);   // prefetch issue
 
-    // ---- MFMA over taps ----
-    constexpr int ZUNROLL = NSUB == 2 ? T3 : 1;
-    // 32 columns: the z loop stays rolled (fully unrolled the scheduler hoists LDS reads and the kernel no longer fits
-    // two workgroups per CU); 64 columns run one workgroup per CU anyway and compile without scratch only unrolled
-#pragma unroll ZUNROLL
-    for (int tz3 = 0; tz3 < T3; ++tz3) {
-     [&]<int... TYX>(std::integer_sequence<int, TYX...>) __attribute__((always_inline)) {
-      ([&]() __attribute__((always_inline)) {
-          constexpr int ty3 = TYX / T3, tx3 = TYX % T3;
-          const int tap = tz3 * T3 * T3 + TYX;
-          if (INTERLEAVE && has_next) {   // wave-uniform: the fetch items of this tap, with compile-time register indices
-            if (tz3 == 0) fetch_range(std::integral_constant<int, TYX * F_PER_TAP>{});
-            else if (tz3 == 1) fetch_range(std::integral_constant<int, (T3 * T3 + TYX) * F_PER_TAP>{});
-            else fetch_range(std::integral_constant<int, (2 * T3 * T3 + TYX) * F_PER_TAP>{});
+    // ---- MFMA over taps, software-pipelined by hand ----
+    // One step = one tap (bf16) or one (tap, 2-channel K-step) (f32): 1 + ... fragments of weights (NSUB) and voxels (4
+    // y-rows), 4 * NSUB MFMAs.  The fragments of step s + 1 are requested before the MFMAs of step s issue (two
+    // register sets, compile-time indices); __builtin_amdgcn_sched_barrier keeps that order, so the live set is what is
+    // written here -- left to the scheduler the loop either waited for each read (lgkmcnt(0) before most MFMAs) or, fully
+    // unrolled, hoisted reads until the kernel no longer fitted two workgroups per CU.
+    {
+      constexpr int NST = TAPS * KSTEPS;
+      typedef typename std::conditional<sizeof(T) == 2, bf16x8, float>::type FragT;
+      FragT wf[2][NSUB], af[2][4];
+      auto load_step = [&](auto st_c) __attribute__((always_inline)) {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr (st < NST) {
+          constexpr int tap = st / KSTEPS, ks = st % KSTEPS, b = st & 1;
+          constexpr int tz3 = tap / (T3 * T3), ty3 = (tap / T3) % T3, tx3 = tap % T3;
+          constexpr int voff = ((tz3 * HALO) * HY + ty3 * HALO) * HX + tx3 * HALO;
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns)
+              wf[b][ns] = *reinterpret_cast<const bf16x8*>(wfrag0 + (tap * 2 * NCOL + ns * 32) * 16);
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+              af[b][ms] = *reinterpret_cast<const bf16x8*>(afrag0 + (voff + ms * HX) * 16);
+          } else {
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns)
+              wf[b][ns] = *reinterpret_cast<const float*>(wfrag0 + ((tap * 4 + ks) * 2 * NCOL + ns * 32) * 4);
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+              af[b][ms] = *reinterpret_cast<const float*>(afrag0 + (ks >> 1) * PLANE + 8 * (ks & 1) + (voff + ms * HX) * 16);
           }
-          const int vbase = ((wave + tz3 * HALO) * HY + ty3 * HALO) * HX + tx3 * HALO + col;
+        }
+      };
+      load_step(std::integral_constant<int, 0>{});
+      [&]<int... ST>(std::integer_sequence<int, ST...>) __attribute__((always_inline)) {
+        ([&]() __attribute__((always_inline)) {
+          constexpr int b = ST & 1;
+          load_step(std::integral_constant<int, ST + 1>{});
+          __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of this step's MFMAs)
+          if constexpr (INTERLEAVE && (ST % KSTEPS) == 0) {
+            if (has_next) fetch_range(std::integral_constant<int, (ST / KSTEPS) * F_PER_TAP>{});   // wave-uniform
+          }
 #pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks) {
-            if constexpr (sizeof(T) == 2) {
-              bf16x8 bfr[NSUB];
+          for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-              for (int ns = 0; ns < NSUB; ++ns)
-                bfr[ns] = *reinterpret_cast<const bf16x8*>(w_tile + ((tap * 2 + h) * NCOL + ns * 32 + col) * 16);
-#pragma unroll
-              for (int ms = 0; ms < 4; ++ms) {
-                const int vox = vbase + ms * HX;
-                const bf16x8 afr =
-                    *reinterpret_cast<const bf16x8*>(in_tile + vox * 32 + 16 * (h ^ ((vox >> 3) & 1)));
-#pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns)
-                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ns], afr, acc[ms][ns], 0, 0, 0);
-              }
-            } else {
-              float bfr[NSUB];
-#pragma unroll
-              for (int ns = 0; ns < NSUB; ++ns)
-                bfr[ns] = *reinterpret_cast<const float*>(w_tile + (((tap * 4 + ks) * 2 + h) * NCOL + ns * 32 + col) * 4);
-#pragma unroll
-              for (int ms = 0; ms < 4; ++ms) {
-                const int vox = vbase + ms * HX;
-                const float afr = *reinterpret_cast<const float*>(
-                    in_tile + vox * 32 + 16 * ((ks >> 1) ^ ((vox >> 3) & 1)) + 4 * (2 * (ks & 1) + h));
-#pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns)
-                  acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[ns], afr, acc[ms][ns], 0, 0, 0);
-              }
+            for (int ns = 0; ns < NSUB; ++ns) {
+              if constexpr (sizeof(T) == 2)
+                acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b][ns], af[b][ms], acc[ms][ns], 0, 0, 0);
+              else
+                acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[b][ns], af[b][ms], acc[ms][ns], 0, 0, 0);
             }
-          }
-      }(), ...);
-     }(std::make_integer_sequence<int, T3 * T3>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }(), ...);
+      }(std::make_integer_sequence<int, NST>{});
     }
     STAMP(5);   // MFMA block of this chunk
   }

@@ -282,6 +282,7 @@ wgrad_kernel(WgArgs a) {
           constexpr int ti = ST % NT, rk = ST / NT;
           load_a(std::integral_constant<int, ST + 2>{});
           if constexpr (ti == 0) load_b(std::integral_constant<int, rk + 1>{});
+          __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of this step's MFMA)
           const bf16x8 afr = __builtin_shufflevector(abuf[ST % 3][0], abuf[ST % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
           const bf16x8 bfr = __builtin_shufflevector(bbuf[rk % 2][0], bbuf[rk % 2][1], 0, 1, 2, 3, 4, 5, 6, 7);
           acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
