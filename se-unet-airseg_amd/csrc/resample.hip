@@ -222,6 +222,96 @@ __global__ void upsample2_bwd_kernel(const T* __restrict__ g_out, int C, T* g_in
   }
 }
 
+// Tiled, separable form of the same transposed interpolation (the form the network uses).  The gather above spends its
+// time evaluating ~7^3 candidate weights and issuing up to 64 16-byte loads per lane.  The trilinear weight factorises,
+// so a block first reduces z and y for the fine x-columns its coarse tile touches (<= 16 loads per item, coalesced
+// along x and channels) into LDS, then reduces x from LDS (<= 4 reads per item): ~4x fewer L1 transactions and ~6x
+// fewer weight evaluations, no temporary tensor in HBM.
+constexpr int UB_TX = 16, UB_XF = 44;   // coarse x per block; fine x columns a tile can touch (2.0625 * 17 + 4 < 44)
+template <typename T, int TY>
+__global__ void __launch_bounds__(256)
+upsample2_bwd_tiled_kernel(const T* __restrict__ g_out, int C, T* g_in, int accumulate, int D, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float us[];   // [TY][UB_XF][C]
+  const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
+  const int x0 = blockIdx.x * UB_TX, y0 = blockIdx.y * TY;
+  const int z = blockIdx.z % D;
+  const long long n = blockIdx.z / D;
+  const int x1 = (x0 + UB_TX < W ? x0 + UB_TX : W) - 1;
+  int xf0, xf1, t0, t1;
+  ac_range(x0, rx, Wo, xf0, t0);
+  ac_range(x1, rx, Wo, t1, xf1);
+  const int nxf = xf1 - xf0 + 1;          // <= UB_XF (checked by the launcher's choice of UB_TX / UB_XF)
+  int zl, zh;
+  ac_range(z, rz, Do, zl, zh);
+  // the z weights of the block's plane and the y weights of its TY rows, evaluated once (not per item and candidate)
+  __shared__ float wzs[12], wys[TY][12];
+  __shared__ int yls[TY], yhs[TY];
+  if (threadIdx.x < 12) wzs[threadIdx.x] = (zl + (int)threadIdx.x <= zh) ? ac_weight(zl + (int)threadIdx.x, z, rz, D) : 0.f;
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + TY * 12) {
+    const int yi = (threadIdx.x - 64) / 12, k = (threadIdx.x - 64) % 12, y = y0 + yi;
+    int yl = 0, yh = -1;
+    if (y < H) ac_range(y, ry, Ho, yl, yh);
+    wys[yi][k] = (yl + k <= yh) ? ac_weight(yl + k, y, ry, H) : 0.f;
+    if (k == 0) { yls[yi] = yl; yhs[yi] = yh < yl + 11 ? yh : yl + 11; }
+  }
+  __syncthreads();
+  const int zh_c = zh < zl + 11 ? zh : zl + 11;   // (the candidate range is at most 9 wide)
+  // phase 1: reduce z and y
+  for (int item = threadIdx.x; item < TY * nxf * G; item += 256) {
+    const int g = item % G;
+    int r = item / G;
+    const int xi = r % nxf, yi = r / nxf;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int yl = yls[yi], yh = yhs[yi];
+    for (int zo = zl; zo <= zh_c; ++zo) {
+      const float wz = wzs[zo - zl];
+      if (wz == 0.f) continue;
+      for (int yo = yl; yo <= yh; ++yo) {
+        const float wy = wys[yi][yo - yl];
+        if (wy == 0.f) continue;
+        float v[8];
+        load8(g_out + ((((n * Do + zo) * Ho + yo) * Wo + (xf0 + xi)) * (long long)C) + g * 8, v);
+        const float w = wz * wy;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+      }
+    }
+    float* q = us + (yi * UB_XF + xi) * C + g * 8;
+    reinterpret_cast<float4*>(q)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    reinterpret_cast<float4*>(q)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+  __syncthreads();
+  // phase 2: reduce x
+  for (int item = threadIdx.x; item < TY * UB_TX * G; item += 256) {
+    const int g = item % G;
+    int r = item / G;
+    const int xi = r % UB_TX, yi = r / UB_TX;
+    const int x = x0 + xi, y = y0 + yi;
+    if (x >= W || y >= H) continue;
+    int xl, xh;
+    ac_range(x, rx, Wo, xl, xh);
+    T* p = g_in + ((((n * D + z) * H + y) * W + x) * (long long)C) + g * 8;
+    float acc[8];
+    if (accumulate) load8(p, acc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    }
+    for (int xo = xl; xo <= xh; ++xo) {
+      const float wx = ac_weight(xo, x, rx, W);
+      if (wx == 0.f) continue;
+      const float* q = us + (yi * UB_XF + (xo - xf0)) * C + g * 8;
+      const float4 a = reinterpret_cast<const float4*>(q)[0], b = reinterpret_cast<const float4*>(q)[1];
+      acc[0] += wx * a.x; acc[1] += wx * a.y; acc[2] += wx * a.z; acc[3] += wx * a.w;
+      acc[4] += wx * b.x; acc[5] += wx * b.y; acc[6] += wx * b.z; acc[7] += wx * b.w;
+    }
+    store8(p, acc);
+  }
+}
+
 // ---------------- side map up-sampling to NCDHW (block-level API / tests only) ------------------
 __global__ void side_upsample_kernel(const float* __restrict__ side, int C, int scale,
                                      float* __restrict__ out, int c_total, int c_off, int D, int H, int W,
@@ -396,9 +486,24 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims d, hi
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
+template <typename T, int TY>
+static void upsample2_bwd_tiled(const void* g_out, int C, void* g_in, int accumulate, Dims d, hipStream_t s) {
+  dim3 grid((unsigned)((d.W + UB_TX - 1) / UB_TX), (unsigned)((d.H + TY - 1) / TY), (unsigned)((long long)d.N * d.D));
+  const size_t lds = (size_t)TY * UB_XF * C * sizeof(float);
+  upsample2_bwd_tiled_kernel<T, TY><<<grid, 256, lds, s>>>((const T*)g_out, C, (T*)g_in, accumulate, d.D, d.H, d.W);
+}
+
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate, Dims d,
                          hipStream_t s) {
   SEUNET_CHECK(C % 8 == 0, "upsample2: C=%d must be a multiple of 8", C);
+  // tiled separable kernel: LDS = TY * 44 * C floats <= 45 KB with TY = 4 up to 64 channels, TY = 2 up to 128
+  const bool tiled = C <= 128 && (long long)d.N * d.D <= 65535 && d.W >= 2;
+  if (tiled) {
+    if (dtype == SEUNET_BF16) { if (C <= 64) upsample2_bwd_tiled<bf16_t, 4>(g_out, C, g_in, accumulate, d, s); else upsample2_bwd_tiled<bf16_t, 2>(g_out, C, g_in, accumulate, d, s); }
+    else { if (C <= 64) upsample2_bwd_tiled<float, 4>(g_out, C, g_in, accumulate, d, s); else upsample2_bwd_tiled<float, 2>(g_out, C, g_in, accumulate, d, s); }
+    SEUNET_LAUNCH_CHECK();
+    return 0;
+  }
   const long long total = (long long)d.N * d.vox() * (C / 8);
   if (dtype == SEUNET_BF16)
     upsample2_bwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)g_out, C, (bf16_t*)g_in, accumulate, d.D, d.H, d.W, total);
