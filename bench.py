@@ -93,7 +93,7 @@ def main():
     model = A.SE_UNet(in_channel=args.in_channel, n_classes=1, width_mult=args.width, act_dtype=args.dtype).to(dev)
     model.eval()      # DropLayer off (parity configuration); everything else is identical in train()
     ddp.broadcast_parameters(model)
-    opt = None if args.no_optimizer else torch.optim.AdamW(model.parameters(), lr=1e-4)
+    opt = None if args.no_optimizer else torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
     group = True if world > 1 else None
 
     g = torch.Generator(device=dev)

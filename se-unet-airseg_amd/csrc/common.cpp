@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace seunet {
@@ -45,6 +46,22 @@ void prof_mark(const char* tag, hipStream_t s) {
   (void)hipEventRecord(p.pool[p.used], s);
   p.marks.emplace_back(tag, p.used);
   ++p.used;
+}
+// ---- a per-device page of zeros: source of padding voxels / channels for the weight-gradient LDS-DMA -------------
+// (one hipMalloc + hipMemset per device for the life of the process, instead of a fill kernel in every launch)
+const void* device_zero_page() {
+  static std::mutex mu;
+  static void* page[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (page[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    page[dev] = p;
+  }
+  return page[dev];
 }
 }  // namespace seunet
 

@@ -397,6 +397,8 @@ struct Exec {
       if (int e = launch_head_bwd(g_pred0, ge, 4, fat(p.head_tmp), grads[find_param(reg, "dc0_0.bias")], p.dims[0], s)) return e;
       if (int e = launch_head_bwd(g_pred1, gd, 3, fat(p.head_tmp), grads[find_param(reg, "dc0_1.bias")], p.dims[0], s)) return e;
     }
+    std::vector<float*> zero_ptrs;
+    std::vector<int> zero_counts;
     for (int i = kNumOps - 1; i >= 0; --i) {
       const OpDesc& o = kOps[i];
       const OpRes& r = p.op[i];
@@ -439,8 +441,9 @@ struct Exec {
         if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd, fat(p.m1), fat(p.m2),
                                    at(p.grad[o.dst]), nullptr, nullptr, dm, s)) return e;
         written[o.dst] = true;
-        // conv1.bias feeds an affine-less InstanceNorm: its gradient is identically zero
-        if (float* gb = grads[find_param(reg, n + ".conv1.bias")]) SEUNET_HIP(hipMemsetAsync(gb, 0, (size_t)r.cout * 4, s));
+        // conv1.bias feeds an affine-less InstanceNorm: its gradient is identically zero; zeroed in one
+        // launch after the loop
+        if (float* gb = grads[find_param(reg, n + ".conv1.bias")]) { zero_ptrs.push_back(gb); zero_counts.push_back(r.cout); }
         if (int e = conv_backward(i, srcs(o), grads, written)) return e;
       } else {  // OP_CAT
         SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
@@ -476,6 +479,10 @@ struct Exec {
         }
         if (int e = conv_backward(i, srcs(o), grads, written)) return e;
       }
+    }
+    if (!zero_ptrs.empty()) {
+      mark("stats");
+      if (int e = launch_multi_zero(zero_ptrs.data(), zero_counts.data(), (int)zero_ptrs.size(), s)) return e;
     }
     mark("outside");
     return 0;

@@ -513,6 +513,24 @@ int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int ac
   return 0;
 }
 
+// zero several small f32 arrays with ONE launch (the identically-zero conv1.bias gradients of a backward pass: a
+// hipMemsetAsync each is a 5-us fill kernel, thirty times per step)
+struct ZeroList { float* ptr[48]; int count[48]; int n; };
+__global__ void multi_zero_kernel(ZeroList z) {
+  float* p = z.ptr[blockIdx.x];
+  for (int i = threadIdx.x; i < z.count[blockIdx.x]; i += blockDim.x) p[i] = 0.f;
+}
+int launch_multi_zero(float* const* ptrs, const int* counts, int n, hipStream_t s) {
+  for (int base = 0; base < n; base += 48) {
+    ZeroList z{};
+    z.n = n - base < 48 ? n - base : 48;
+    for (int i = 0; i < z.n; ++i) { z.ptr[i] = ptrs[base + i]; z.count[i] = counts[base + i]; }
+    multi_zero_kernel<<<z.n, 256, 0, s>>>(z);
+  }
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_side_upsample(const float* side, int C, int scale, float* out, int c_total, int c_off, Dims dl,
                          hipStream_t s) {
   const long long total = (long long)dl.N * dl.vox() * scale * scale * scale;

@@ -436,9 +436,9 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   a.cum1 = x.n > 1 ? x.C[0] : x.total();
   a.cum2 = x.n > 2 ? x.C[0] + x.C[1] : x.total();
   a.dy = dy; a.cout = cout;
-  a.zero = workspace;
+  a.zero = device_zero_page();
+  SEUNET_CHECK(a.zero != nullptr, "wgrad: cannot allocate the device zero page");
   a.slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + 256);
-  SEUNET_HIP(hipMemsetAsync(workspace, 0, 256, s));
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const int tz = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TZ : WgTile<float>::TZ;
   const int ty = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TY : WgTile<float>::TY;
