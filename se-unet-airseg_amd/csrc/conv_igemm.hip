@@ -694,8 +694,8 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   const int st = taps == 27 ? dil : 1;
   a.tx = cdiv(cdiv(d.W, st), CV_TX); a.ty = cdiv(cdiv(d.H, st), CV_TY); a.tz = cdiv(cdiv(d.D, st), CV_TZ);
   a.nchunks = cdiv(a.cin, conv_kc(dtype));
-  a.direct = 1;
-  for (int i = 0; i < dst.n; ++i) if (dst.C[i] > 16) a.direct = 0;
+  a.direct = 1;   // voxel pitch of every destination <= 32 B (dilation 2 writes every other voxel: pitch doubles)
+  for (int i = 0; i < dst.n; ++i) if (dst.C[i] * st > 16) a.direct = 0;
   a.debug = g_conv_debug;
   const int ncol = conv_ncol(a.cin, a.cout);
   dim3 grid(a.tx * a.ty * a.tz * st * st * st, cdiv(a.cout, ncol), d.N);
