@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--in-channel", type=int, default=2)
     ap.add_argument("--width", type=int, default=1)
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="torch.optim.AdamW instead of the fused seunet AdamW (SURVEY 8(f1))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--cpu-size", type=int, default=128)
@@ -93,7 +94,7 @@ def main():
     model = A.SE_UNet(in_channel=args.in_channel, n_classes=1, width_mult=args.width, act_dtype=args.dtype).to(dev)
     model.eval()      # DropLayer off (parity configuration); everything else is identical in train()
     ddp.broadcast_parameters(model)
-    opt = None if args.no_optimizer else torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    opt = None if args.no_optimizer else (torch.optim.AdamW(model.parameters(), lr=1e-4) if args.torch_optimizer else A.AdamW(model.parameters(), lr=1e-4))
     group = True if world > 1 else None
 
     g = torch.Generator(device=dev)

@@ -125,6 +125,17 @@ int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, 
                      long long n, const double* sums, float c_dice, float c_gul, float c_atr, float g_scale,
                      const float* g_scale_dev, float* g_pred, seunet_stream_t s);
 
+/* ---- optimizer step: torch.optim.AdamW(model.parameters(), lr=0.0001).step() -----------------
+ * Replaces optimizer.step() at train.py:247,439,603 (constructed at train.py:188,386,569 with PyTorch's default
+ * betas=(0.9,0.999), eps=1e-8, weight_decay=0.01, amsgrad=False).  All n tensors of a step are updated by
+ * ceil(n/24) launches; pointer arrays are HOST arrays of DEVICE pointers to contiguous f32 tensors of counts[i]
+ * elements.  `step` counts from 1 (the value of state['step'] AFTER the increment).  lr is passed per call, so
+ * torch.optim.lr_scheduler.MultiStepLR (train.py:189-191) keeps working on the host side.  Hyper-parameters are
+ * doubles because PyTorch forms 1-beta, 1-lr*wd and the bias corrections in double before rounding to f32. */
+int seunet_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const long long* counts, int n_tensors, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, int step, int maximize, seunet_stream_t s);
+
 /* ---- whole network: SE_UNet.forward (SE_UNet.py:181-238) and its backward ------------------------------- */
 typedef struct seunet_net_desc {
   int batch, in_channel, n_classes;

@@ -175,4 +175,12 @@ int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, 
   return launch_loss_grad(pred, apply_sigmoid, target, weight, skel, n, sums, c_dice, c_gul, c_atr, g_scale, g_scale_dev, g_pred, S(s));
 }
 
+int seunet_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const long long* counts, int n_tensors, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, int step, int maximize, seunet_stream_t s) {
+  SEUNET_CHECK(n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && counts), "adamw_step: bad argument");
+  return launch_adamw(params, grads, exp_avg, exp_avg_sq, counts, n_tensors, lr, beta1, beta2, eps, weight_decay, step,
+                      maximize, S(s));
+}
+
 }  // extern "C"

@@ -238,6 +238,9 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, 
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate,
                          Dims din, hipStream_t s);
 int launch_multi_zero(float* const* ptrs, const int* counts, int n, hipStream_t s);
+int launch_adamw(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const long long* counts, int n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 int step, int maximize, hipStream_t s);
 const void* device_zero_page();   // >= 256 zero bytes on the current device (allocated once per device, never freed)
 int launch_side_upsample(const float* side, int C, int scale, float* out_ncdhw, int c_total,
                          int c_off, Dims dlow, hipStream_t s);

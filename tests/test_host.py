@@ -127,3 +127,23 @@ def test_data_parallel_exchange_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
+
+
+def test_adamw_surface_and_no_cpu_path():
+    """optim.AdamW mirrors torch.optim.AdamW's constructor / param_groups and refuses CPU tensors."""
+    import seunet_amd as A
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = A.AdamW([p], lr=1e-4)
+    ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(4))], lr=1e-4)
+    for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"):
+        assert opt.param_groups[0][k] == ref.param_groups[0][k], k
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)   # train.py:189-191 works on it
+    sched.step()
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-5)
+    with pytest.raises(ValueError):
+        A.AdamW([p], amsgrad=True)
+    with pytest.raises(ValueError):
+        A.AdamW([p], lr=-1.0)
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError):     # no CPU fallback: either the library is missing or the tensor is not on the GPU
+        opt.step()

@@ -131,3 +131,20 @@ def test_two_channel():
     c0, c1 = orc.two_channel(hu)
     np.testing.assert_allclose(c0, [0, 0, 24 / 2048, 0.5, 1524 / 2048, 1, 1])
     np.testing.assert_allclose(c1, [0, 0, 0, 1000 / 1500, 1, 1, 1])
+
+
+def test_adamw_oracle_matches_torch_adamw_fixture(golden_dir):
+    """oracle/adamw_oracle.py against torch.optim.AdamW + MultiStepLR outputs (oracle/make_golden_adamw.py)."""
+    import adamw_oracle as ao
+    d = _load(golden_dir, "adamw_known.npz")
+    n, steps = int(d["n"]), int(d["steps"])
+    lrs = list(d["lrs"])
+    assert lrs[0] == 1e-4 and lrs[2] == pytest.approx(1e-5) and lrs[4] == pytest.approx(1e-6)   # MultiStepLR inside the fixture
+    assert [ao.multistep_lr(1e-4, e, (2, 4)) for e in range(5)] == pytest.approx(lrs)
+    res = ao.run([d[f"init_{i}"] for i in range(n)], [[d[f"grad_{t}_{i}"] for i in range(n)] for t in range(steps)], lrs)
+    for i in range(n):
+        np.testing.assert_array_equal(res["params"][i], d[f"final_{i}"])                      # bit-exact parameters
+        # moments: the vectorised torch kernels contract multiply-adds differently -> a rounding of the largest element
+        for k in ("exp_avg", "exp_avg_sq"):
+            ref = d[f"{k}_{i}"]
+            np.testing.assert_allclose(res[k][i], ref, rtol=1e-6, atol=2e-7 * float(np.abs(ref).max()))
