@@ -55,6 +55,7 @@ struct ConvKArgs {
   int N, D, H, W;
   int tx, ty, tz;            // tile counts (on the sub-lattice when dilated)
   int nchunks;
+  int pair;                  // 1: both 16-B pieces of every channel chunk come from one source tensor (lane-pair staging)
   int direct;                // 1: every destination has <= 16 channels (stores straight from the accumulators)
   unsigned long long* debug;   // diagnostic builds only (-DSEUNET_STAMP): per-phase cycle sums
 };
@@ -106,7 +107,7 @@ conv_igemm_kernel(ConvKArgs a) {
   constexpr int W_ITEMS = (W_TOTAL + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* in_tile = smem;
-  unsigned char* w_tile = smem + IN_ITEMS * 4096;
+  unsigned char* w_tile = smem + IN_ITEMS * 4096 + 128;   // after the two (64-B padded) input planes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
@@ -127,14 +128,19 @@ conv_igemm_kernel(ConvKArgs a) {
   const long long V = (long long)a.D * a.H * a.W;
 
   // ---- per-thread staging plan (chunk independent) ----
-  // staging slot L = tid + 256*k: wave-instruction (wave, k) moves piece (wave & 1) of the 64 consecutive halo
-  // voxels starting at (2k + (wave >> 1)) * 64, so the piece -- hence the source tensor -- is wave-uniform.
-  const int piece = wave & 1;
+  // A staging instruction moves 64 16-byte pieces.  Paired mode (a.pair; whenever the two pieces of every 32-B channel
+  // chunk come from the same source tensor): lanes (2i, 2i+1) take both pieces of one voxel -- 32 contiguous bytes, 32
+  // voxels per instruction -- which halves the cache lines an instruction touches; the fetch phase is bound by the
+  // texture path at about one line per clock.  Otherwise (a concatenation boundary inside a chunk) the piece is
+  // wave-uniform (wave & 1) and an instruction covers 64 consecutive voxels.
+  const bool pair = a.pair != 0;                                   // wave-uniform
+  const int piece = pair ? (lane & 1) : (wave & 1);
+  const int vox0 = pair ? wave * 32 + (lane >> 1) : (wave >> 1) * 64 + lane;   // voxel of item k: vox0 + 128 * k
   constexpr unsigned INVALID = 0xFFFFFFFFu;
   unsigned vofs[IN_ITEMS];
 #pragma unroll
   for (int k = 0; k < IN_ITEMS; ++k) {
-    const int vox = (2 * k + (wave >> 1)) * 64 + lane;
+    const int vox = vox0 + 128 * k;
     const int hx = vox % HX;
     const int r2 = vox / HX;
     const int hy = r2 % HY, hz = r2 / HY;
@@ -147,8 +153,8 @@ conv_igemm_kernel(ConvKArgs a) {
   // LDS image of the halo tile: planar, [16-B piece of the 32-B chunk][voxel][16 B] -- a staging instruction writes 1 KB
   // contiguous, an MFMA fragment read (32 consecutive voxels of one piece) is 512 B contiguous: both conflict-free with
   // no swizzle, so every fragment address is "lane base + compile-time offset" (the offset field of ds_read)
-  constexpr int PLANE = IN_ITEMS * 2048;
-  const int lds_in0 = piece * PLANE + ((wave >> 1) * 64 + lane) * 16;   // + k * 2048
+  constexpr int PLANE = IN_ITEMS * 2048 + 64;   // (+64 B: in paired mode even / odd lanes write different planes; keeps them on different banks)
+  const int lds_in0 = piece * PLANE + vox0 * 16;   // + k * 2048
   // fragment bases of this lane: voxel (z-slice of the wave, x = col), k-half h
   const unsigned char* afrag0 = in_tile + (sizeof(T) == 2 ? h * PLANE : 4 * h) + (wave * HY * HX + col) * 16;
   const unsigned char* wfrag0 = w_tile + (h * NCOL + col) * (sizeof(T) == 2 ? 16 : 4);
@@ -165,8 +171,11 @@ conv_igemm_kernel(ConvKArgs a) {
   // hold the wave for ~1.5k cycles (the texture path takes 16+ cycles per 1-KB instruction) with the matrix pipe idle.
   __amdgpu_buffer_rsrc_t rs_in, rs_w;
   unsigned in_stride = 0;
+  unsigned pofs = 0;        // paired mode: byte offset of this lane's piece inside the chunk
+  bool pbad = false;        // paired mode: this lane's piece lies beyond the last input channel (reads zeros)
   auto fetch_setup = [&](int chunk) __attribute__((always_inline)) {
-    const int ch0 = chunk * KC + piece * (KC / 2);
+    const int chb = chunk * KC;                                   // first channel of the chunk
+    const int ch0 = pair ? chb : chb + piece * (KC / 2);          // (unpaired: piece is wave-uniform)
     const void* sp = a.src0; int sC = a.srcC0, c = ch0;
     if (ch0 >= a.cum2) { sp = a.src2; sC = a.srcC2; c = ch0 - a.cum2; }
     else if (ch0 >= a.cum1) { sp = a.src1; sC = a.srcC1; c = ch0 - a.cum1; }
@@ -175,6 +184,10 @@ conv_igemm_kernel(ConvKArgs a) {
     rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(base)), 0,
                                               __builtin_amdgcn_readfirstlane((int)avail), 0x00020000);
     in_stride = __builtin_amdgcn_readfirstlane((unsigned)(sC * (int)sizeof(T)));
+    if (pair) {
+      pofs = (unsigned)piece * 16u;
+      pbad = piece == 1 && chb + KC / 2 >= a.cin;
+    }
     rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(wbase + (size_t)chunk * (W_TOTAL * 16))), 0,
                                              W_TOTAL * 16, 0x00020000);
   };
@@ -183,11 +196,12 @@ conv_igemm_kernel(ConvKArgs a) {
     if constexpr (item < IN_ITEMS) {
       // byte offset = voxel index x stride, formed at the point of issue from a fresh copy of the stride (the empty asm
       // keeps the compiler from hoisting all IN_ITEMS products out of the tap loop into 10 more live registers).
-      // Padding voxels carry index 0xFFFFFFFF: the product wraps to 2^32 - stride, beyond any tensor the 32-bit range
-      // check admits (launch_conv_igemm rejects >= 2^31-byte samples), so the hardware returns zeros.
+      // Padding voxels carry index 0xFFFFFFFF: the product wraps to 2^32 - stride (+ < stride), beyond any tensor the
+      // 32-bit range check admits (launch_conv_igemm rejects >= 2^31-byte samples), so the hardware returns zeros.
       unsigned st = in_stride;
       asm volatile("" : "+s"(st));
-      rin[item] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vofs[item] * st, 0, 0);
+      const unsigned off = pbad ? 0x80000000u : vofs[item] * st + pofs;
+      rin[item] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
     } else if constexpr (item < IN_ITEMS + W_ITEMS) {
       constexpr int k = item - IN_ITEMS;
       rw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)tid * 16u, k * 4096, 0);
@@ -334,7 +348,7 @@ conv_igemm_kernel(ConvKArgs a) {
   //     16 sums of squares) are reduced over the 32 voxel lanes of each half-wave by a reduce-scatter on DPP:
   //     5 steps of "keep half of my values, add the partner's copy of them", partners l^16, l^8, l^7, l^2, l^1
   //     (ds_swizzle, row_ror:8, row_half_mirror, quad_perm), after which lane j of a half owns value j.
-  constexpr int K_BYTES = (IN_ITEMS + W_ITEMS) * 4096;     // the K-loop tiles; slower waves may still be reading them
+  constexpr int K_BYTES = (IN_ITEMS + W_ITEMS) * 4096 + 128;   // the K-loop tiles; slower waves may still be reading them
   constexpr int E_BYTES = 4 * 128 * (NCOL * (int)sizeof(T) + 16);   // the four waves' store stages (step 3)
   double* red = reinterpret_cast<double*>(smem + (K_BYTES > E_BYTES ? K_BYTES : E_BYTES));   // [4 waves][NCOL][2]
   if (a.stats != nullptr) {
@@ -639,7 +653,7 @@ template <typename T, int NSUB, int TAPS, int DIL>
 static int launch_one(const ConvKArgs& a, dim3 grid, hipStream_t s) {
   constexpr int HALO = (TAPS == 27) ? 1 : 0;
   constexpr int NVH = (CV_TZ + 2 * HALO) * (CV_TY + 2 * HALO) * (CV_TX + 2 * HALO);
-  constexpr int LDS_K = ((NVH * 2 + 255) / 256 + (TAPS * 64 * NSUB + 255) / 256) * 4096;   // K-loop tiles, padded to whole staging rounds
+  constexpr int LDS_K = ((NVH * 2 + 255) / 256 + (TAPS * 64 * NSUB + 255) / 256) * 4096 + 128;   // K-loop tiles, padded to whole staging rounds
   constexpr int LDS_E = 4 * 128 * (32 * NSUB * (int)sizeof(T) + 16);                       // the four waves' store stages
   constexpr int LDS = (LDS_K > LDS_E ? LDS_K : LDS_E) + 4 * 32 * NSUB * 16;                // + the statistics partials
   static bool configured = false;  // per instantiation
@@ -694,6 +708,10 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   const int st = taps == 27 ? dil : 1;
   a.tx = cdiv(cdiv(d.W, st), CV_TX); a.ty = cdiv(cdiv(d.H, st), CV_TY); a.tz = cdiv(cdiv(d.D, st), CV_TZ);
   a.nchunks = cdiv(a.cin, conv_kc(dtype));
+  {  // lane-pair staging needs the concatenation boundaries on chunk boundaries (always true for f32: chunk = 8 channels)
+    const int kc = conv_kc(dtype);
+    a.pair = (a.cum1 % kc == 0 || a.cum1 >= a.cin) && (a.cum2 % kc == 0 || a.cum2 >= a.cin) ? 1 : 0;
+  }
   a.direct = 1;   // voxel pitch of every destination <= 32 B (dilation 2 writes every other voxel: pitch doubles)
   for (int i = 0; i < dst.n; ++i) if (dst.C[i] * st > 16) a.direct = 0;
   a.debug = g_conv_debug;
