@@ -11,8 +11,20 @@
 
 namespace seunet {
 
-static constexpr int LOSS_BLOCKS = 512;
+static constexpr int LOSS_BLOCKS = 1024;   // 4 per CU; each thread handles n / (1024 * 256) elements, 4 per load
 int loss_partials() { return LOSS_BLOCKS; }
+
+__device__ __forceinline__ void loss_terms(float p, int apply_sigmoid, float t, float w, float sk, float (&s)[SEUNET_LOSS_NSUMS]) {
+  if (apply_sigmoid) p = 1.f / (1.f + expf(-p));
+  s[0] += p * t;
+  s[1] += p;
+  s[2] += t;
+  if (t != 0.f) s[3] += w * powf(p + 1e-4f, 0.7f) * t;   // (the label is sparse: the pow is skipped where it is multiplied by 0)
+  s[4] += w * (0.2f * p + 0.8f * t);
+  const float ps = p * sk;
+  s[5] += w * ps * sk;
+  s[6] += w * (ps + sk);
+}
 
 __global__ void __launch_bounds__(256)
 loss_sums_kernel(const float* __restrict__ pred, int apply_sigmoid, const float* __restrict__ target,
@@ -21,20 +33,22 @@ loss_sums_kernel(const float* __restrict__ pred, int apply_sigmoid, const float*
   float s[SEUNET_LOSS_NSUMS];
 #pragma unroll
   for (int k = 0; k < SEUNET_LOSS_NSUMS; ++k) s[k] = 0.f;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float p = pred[i];
-    if (apply_sigmoid) p = 1.f / (1.f + expf(-p));
-    const float t = target[i];
-    const float w = weight ? weight[i] : 1.f;
-    const float sk = skel ? skel[i] : 0.f;
-    s[0] += p * t;
-    s[1] += p;
-    s[2] += t;
-    s[3] += w * powf(p + 1e-4f, 0.7f) * t;
-    s[4] += w * (0.2f * p + 0.8f * t);
-    const float ps = p * sk;
-    s[5] += w * ps * sk;
-    s[6] += w * (ps + sk);
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<size_t>(pred) | reinterpret_cast<size_t>(target) |
+                                     reinterpret_cast<size_t>(weight) | reinterpret_cast<size_t>(skel)) & 15) == 0;
+  if (vec) {   // 16-byte loads
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      const float4 p = reinterpret_cast<const float4*>(pred)[i], t = reinterpret_cast<const float4*>(target)[i];
+      const float4 w = weight ? reinterpret_cast<const float4*>(weight)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 k = skel ? reinterpret_cast<const float4*>(skel)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      loss_terms(p.x, apply_sigmoid, t.x, w.x, k.x, s);
+      loss_terms(p.y, apply_sigmoid, t.y, w.y, k.y, s);
+      loss_terms(p.z, apply_sigmoid, t.z, w.z, k.z, s);
+      loss_terms(p.w, apply_sigmoid, t.w, w.w, k.w, s);
+    }
+  } else {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+      loss_terms(pred[i], apply_sigmoid, target[i], weight ? weight[i] : 1.f, skel ? skel[i] : 0.f, s);
   }
   __shared__ float red[4][SEUNET_LOSS_NSUMS];
 #pragma unroll
@@ -51,12 +65,15 @@ loss_sums_kernel(const float* __restrict__ pred, int apply_sigmoid, const float*
   }
 }
 
-__global__ void loss_sums_final_kernel(const float* __restrict__ partial, int blocks, double* __restrict__ sums) {
-  const int k = threadIdx.x;
-  if (k >= SEUNET_LOSS_NSUMS) return;
+// one wave per sum: lane l adds the block partials l, l+64, ... in f64, then a fixed-order butterfly
+__global__ void __launch_bounds__(64 * SEUNET_LOSS_NSUMS)
+loss_sums_final_kernel(const float* __restrict__ partial, int blocks, double* __restrict__ sums) {
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[b * SEUNET_LOSS_NSUMS + k];
-  sums[k] = s;
+  for (int b = lane; b < blocks; b += 64) s += (double)partial[b * SEUNET_LOSS_NSUMS + k];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) sums[k] = s;
 }
 
 // g_pred[i] = g_scale * ( c_dice*d dice/dp + c_gul*d gul/dp + c_atr*d atr/dp ) [* p(1-p)]
@@ -72,32 +89,40 @@ loss_grad_kernel(const float* __restrict__ pred, int apply_sigmoid, const float*
   const float gA = (float)(sums[3] + 1.0), gB = (float)(sums[4] + 1.0);
   // atr = 1 - (C1+1)/(C2+1)
   const float aA = (float)(sums[5] + 1.0), aB = (float)(sums[6] + 1.0);
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float p = pred[i];
+  auto grad1 = [&](float p, float t, float w, float sk) -> float {
     if (apply_sigmoid) p = 1.f / (1.f + expf(-p));
-    const float t = target[i];
     float g = 0.f;
     if (c_dice != 0.f) g += c_dice * (-(2.f * t * dB - dA) / (dB * dB));
     if (c_gul != 0.f) {
-      const float w = weight ? weight[i] : 1.f;
       const float dnum = (t != 0.f) ? 0.7f * w * t * powf(p + 1e-4f, -0.3f) : 0.f;
       g += c_gul * (-(dnum * gB - gA * 0.2f * w) / (gB * gB));
     }
-    if (c_atr != 0.f) {
-      const float w = weight ? weight[i] : 1.f;
-      const float sk = skel ? skel[i] : 0.f;
-      g += c_atr * (-(w * sk * sk * aB - aA * w * sk) / (aB * aB));
-    }
+    if (c_atr != 0.f) g += c_atr * (-(w * sk * sk * aB - aA * w * sk) / (aB * aB));
     g *= g_scale;
     if (apply_sigmoid) g *= p * (1.f - p);
-    g_pred[i] = g;
+    return g;
+  };
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<size_t>(pred) | reinterpret_cast<size_t>(target) | reinterpret_cast<size_t>(weight) |
+                                     reinterpret_cast<size_t>(skel) | reinterpret_cast<size_t>(g_pred)) & 15) == 0;
+  if (vec) {
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      const float4 p = reinterpret_cast<const float4*>(pred)[i], t = reinterpret_cast<const float4*>(target)[i];
+      const float4 w = weight ? reinterpret_cast<const float4*>(weight)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 k = skel ? reinterpret_cast<const float4*>(skel)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(g_pred)[i] = make_float4(grad1(p.x, t.x, w.x, k.x), grad1(p.y, t.y, w.y, k.y),
+                                                         grad1(p.z, t.z, w.z, k.z), grad1(p.w, t.w, w.w, k.w));
+    }
+  } else {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+      g_pred[i] = grad1(pred[i], target[i], weight ? weight[i] : 1.f, skel ? skel[i] : 0.f);
   }
 }
 
 int launch_loss_sums(const float* pred, int apply_sigmoid, const float* target, const float* weight,
                      const float* skel, long long n, float* partial, double* sums, hipStream_t s) {
   loss_sums_kernel<<<LOSS_BLOCKS, 256, 0, s>>>(pred, apply_sigmoid, target, weight, skel, n, partial);
-  loss_sums_final_kernel<<<1, 64, 0, s>>>(partial, LOSS_BLOCKS, sums);
+  loss_sums_final_kernel<<<1, 64 * SEUNET_LOSS_NSUMS, 0, s>>>(partial, LOSS_BLOCKS, sums);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

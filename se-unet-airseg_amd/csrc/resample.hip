@@ -401,11 +401,19 @@ __global__ void up_transpose_axis_kernel(const float* __restrict__ in, float* __
   }
 }
 
-// deterministic two-stage sum of an f32 array
+// deterministic two-stage sum of an f32 array (16-byte loads when the array allows it; f64 accumulation)
 __global__ void __launch_bounds__(256) sum_stage1_kernel(const float* __restrict__ in, long long n,
                                                          double* __restrict__ partial) {
   double s = 0.0;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)in[i];
+  if ((n & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0) {
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      const float4 v = reinterpret_cast<const float4*>(in)[i];
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+  } else {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)in[i];
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
   __shared__ double w[4];
@@ -413,12 +421,12 @@ __global__ void __launch_bounds__(256) sum_stage1_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = ((w[0] + w[1]) + w[2]) + w[3];
 }
-__global__ void sum_stage2_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    out[0] = (float)s;
-  }
+__global__ void __launch_bounds__(64) sum_stage2_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (threadIdx.x == 0) out[0] = (float)s;
 }
 
 // ---------------- launchers -----------------------------------------------------------------------
@@ -575,8 +583,8 @@ int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
   }
   if (g_bias) {
     double* part = reinterpret_cast<double*>(tmp + (((size_t)d0.N * V0 + 1) & ~(size_t)1));
-    sum_stage1_kernel<<<256, 256, 0, s>>>(g_pred, (long long)d0.N * V0, part);
-    sum_stage2_kernel<<<1, 64, 0, s>>>(part, 256, g_bias);
+    sum_stage1_kernel<<<1024, 256, 0, s>>>(g_pred, (long long)d0.N * V0, part);
+    sum_stage2_kernel<<<1, 64, 0, s>>>(part, 1024, g_bias);
     SEUNET_LAUNCH_CHECK();
   }
   return 0;
