@@ -584,9 +584,9 @@ conv_igemm_kernel(ConvKArgs a) {
 // transpose_flip = 1 builds the data-gradient operator (roles of Cin/Cout swapped, taps mirrored)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void conv_pack_kernel(const float* __restrict__ w, int taps, int cin_w, int cout_w, int tflip,
-                                 T* __restrict__ out, int cin_e, int cout_e, int nchunks, int ncol,
-                                 long long total) {
+__device__ __forceinline__ void conv_pack_body(const float* __restrict__ w, int taps, int cin_w, int cout_w, int tflip,
+                                               T* __restrict__ out, int cin_e, int cout_e, int nchunks, int ncol,
+                                               long long total) {
   constexpr int KC = Frag<T>::KC;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -615,6 +615,20 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int taps, int cin_
     out[i] = from_f32<T>(v);
   }
 }
+template <typename T>
+__global__ void conv_pack_kernel(const float* __restrict__ w, int taps, int cin_w, int cout_w, int tflip,
+                                 T* __restrict__ out, int cin_e, int cout_e, int nchunks, int ncol,
+                                 long long total) {
+  conv_pack_body<T>(w, taps, cin_w, cout_w, tflip, out, cin_e, cout_e, nchunks, ncol, total);
+}
+// all the weight tensors of a forward (or backward) pass in one launch: blockIdx.y = list entry
+struct PackEntry { const float* w; void* out; int taps, cin_w, cout_w, tflip, cin_e, cout_e, nchunks, ncol; long long total; };
+struct PackList { PackEntry e[24]; };
+template <typename T>
+__global__ void conv_pack_multi_kernel(PackList l) {
+  const PackEntry& e = l.e[blockIdx.y];
+  conv_pack_body<T>(e.w, e.taps, e.cin_w, e.cout_w, e.tflip, reinterpret_cast<T*>(e.out), e.cin_e, e.cout_e, e.nchunks, e.ncol, e.total);
+}
 
 // N columns per workgroup.  64 columns (two MFMA column blocks per A fragment, one workgroup per CU) only pay when
 // the K loop is long; measured on MI355X (scripts/bench_conv.py): 32->64 channel convs run 20-25 % faster as two
@@ -639,6 +653,26 @@ int launch_conv_pack_weights(int dtype, const float* w, int taps, int cin_w, int
     conv_pack_kernel<bf16_t><<<grid, 256, 0, s>>>(w, taps, cin_w, cout_w, tflip, (bf16_t*)wpack, cin_e, cout_e, nchunks, ncol, total);
   else
     conv_pack_kernel<float><<<grid, 256, 0, s>>>(w, taps, cin_w, cout_w, tflip, (float*)wpack, cin_e, cout_e, nchunks, ncol, total);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv_pack_weights_multi(int dtype, const ConvPackJob* jobs, int n, hipStream_t s) {
+  for (int base = 0; base < n; base += 24) {
+    PackList l{};
+    const int m = n - base < 24 ? n - base : 24;
+    for (int i = 0; i < m; ++i) {
+      const ConvPackJob& j = jobs[base + i];
+      SEUNET_CHECK(j.taps == 27 || j.taps == 1, "conv pack: taps=%d unsupported", j.taps);
+      PackEntry& e = l.e[i];
+      e.w = j.w; e.out = j.wpack; e.taps = j.taps; e.cin_w = j.cin_w; e.cout_w = j.cout_w; e.tflip = j.tflip;
+      e.cin_e = j.tflip ? j.cout_w : j.cin_w; e.cout_e = j.tflip ? j.cin_w : j.cout_w;
+      e.ncol = conv_ncol(e.cin_e, e.cout_e); e.nchunks = cdiv(e.cin_e, conv_kc(dtype));
+      e.total = (long long)(conv_wpack_bytes(dtype, j.taps, e.cin_e, e.cout_e) / dtype_size(dtype));
+    }
+    if (dtype == SEUNET_BF16) conv_pack_multi_kernel<bf16_t><<<dim3(64, m), 256, 0, s>>>(l);
+    else conv_pack_multi_kernel<float><<<dim3(64, m), 256, 0, s>>>(l);
+  }
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

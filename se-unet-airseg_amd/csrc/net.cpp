@@ -269,9 +269,7 @@ struct Exec {
       if (int e = launch_channel_stats(p.d.dtype, at(raw_off), cout, dat(p.stats), dm, s)) return e;
       slots = epi_partials(dm);
     } else {
-      mark("pack_w");
-      if (int e = launch_conv_pack_weights(p.d.dtype, w, taps, cin, cout, 0, at(wp_off), s)) return e;
-      mark("conv_fwd:" + nm);
+      mark("conv_fwd:" + nm);   // (weights were packed by pack_all_weights)
       if (int e = launch_conv_igemm(p.d.dtype, taps, dil, src, cin, at(wp_off), bias, dst, dat(p.stats), dm, s)) return e;
       slots = conv_stats_tiles(dm, taps, dil);
     }
@@ -302,7 +300,28 @@ struct Exec {
     return h;
   }
 
+  // every conv weight of a pass repacked into its MFMA layout by one or two launches (the parameters change every step)
+  int pack_all_weights(bool dgrad) {
+    if (p.d.conv_impl == SEUNET_CONV_NAIVE) return 0;
+    std::vector<ConvPackJob> jobs;
+    for (int i = 0; i < kNumOps; ++i) {
+      const OpDesc& o = kOps[i];
+      if (o.kind != OP_GATED && o.kind != OP_CAT) continue;
+      const OpRes& r = p.op[i];
+      const std::string n = o.name;
+      if (!dgrad) {
+        jobs.push_back({P(n + ".conv1.weight"), at(r.wp_f), r.taps, r.cin, r.cout, 0});
+        if (o.kind == OP_CAT && o.xname) jobs.push_back({P(std::string(o.xname) + ".conv1.weight"), at(r.wp_x), 1, p.d.in_channel, r.cout, 0});
+      } else if (r.need_dgrad) {
+        jobs.push_back({P(n + ".conv1.weight"), at(r.wp_d), r.taps, r.cin, r.cout, 1});
+      }
+    }
+    mark("pack_w");
+    return launch_conv_pack_weights_multi(p.d.dtype, jobs.data(), (int)jobs.size(), s);
+  }
+
   int forward(const float* x, const float* drop1, const float* drop2, float* pred0, float* pred1) {
+    if (int e = pack_all_weights(false)) return e;
     mark("pack_input");
     if (int e = launch_pack_input(p.d.dtype, x, p.d.in_channel, at(p.feat[T_X0]), p.dims[0], s)) return e;
     bool lvl_written[2][4] = {{false, false, false, false}, {false, false, false, false}};
@@ -382,11 +401,11 @@ struct Exec {
     mark("dgrad:" + n);
     if (p.d.conv_impl == SEUNET_CONV_NAIVE)
       return launch_conv_naive(p.d.dtype, r.taps, o.dil, gsrc, r.cout, w, 1, nullptr, gd, p.dims[lv], s);
-    if (int e = launch_conv_pack_weights(p.d.dtype, w, r.taps, r.cin, r.cout, 1, at(r.wp_d), s)) return e;
     return launch_conv_igemm(p.d.dtype, r.taps, o.dil, gsrc, r.cout, at(r.wp_d), nullptr, gd, nullptr, p.dims[lv], s);
   }
 
   int backward(const float* g_pred0, const float* g_pred1, const float* drop1, const float* drop2, float* const* grads) {
+    if (int e = pack_all_weights(true)) return e;
     bool written[T_COUNT];
     for (int t = 0; t < T_COUNT; ++t) written[t] = false;
     // heads: level gradients = transposed interpolation of the logit gradients

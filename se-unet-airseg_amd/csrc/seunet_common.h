@@ -169,6 +169,8 @@ size_t conv_wpack_bytes(int dtype, int taps, int cin, int cout);
 int launch_conv_pack_weights(int dtype, const float* w_torch, int taps, int cin_w, int cout_w,
                              int transpose_flip, void* wpack, hipStream_t s);
 int conv_stats_tiles(Dims d, int taps, int dil);   // partial-stat slots per sample written by the igemm kernel
+struct ConvPackJob { const float* w; void* wpack; int taps, cin_w, cout_w, tflip; };
+int launch_conv_pack_weights_multi(int dtype, const ConvPackJob* jobs, int n, hipStream_t s);
 int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_logical,
                       const void* wpack, const float* bias, const DstList& dst,
                       double* stats_partial, Dims d, hipStream_t s);
