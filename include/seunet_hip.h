@@ -136,6 +136,14 @@ int seunet_adamw_step(float* const* params, const float* const* grads, float* co
                       const long long* counts, int n_tensors, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, int maximize, seunet_stream_t s);
 
+/* ---- post-processing: double_threshold_iteration, prediction.py:13-37 (= train.py:25-49) -------
+ * pred: (h, w, z) float64 probabilities on the device (the overlap-averaged volume, prediction.py:109); out: h*w*z
+ * bytes, 1 where the reference's result is 1.0.  Reproduces the reference's single in-place raster-order sweep
+ *  bit for bit.  workspace: seunet_dti_workspace_bytes(h, w, z) bytes, caller-owned. */
+size_t seunet_dti_workspace_bytes(int h, int w, int z);
+int seunet_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out,
+               void* workspace, size_t workspace_bytes, seunet_stream_t s);
+
 /* ---- whole network: SE_UNet.forward (SE_UNet.py:181-238) and its backward ------------------------------- */
 typedef struct seunet_net_desc {
   int batch, in_channel, n_classes;

@@ -5,12 +5,13 @@ hand-written HIP kernels behind a C ABI (``include/seunet_hip.h``).  The directo
 Python identifier; import it as ``seunet_amd`` (alias module at the repo root) or via
 ``importlib.import_module("se-unet-airseg_amd")``.
 """
-from . import _lib, ddp, ops, optim
+from . import _lib, ddp, ops, optim, postprocess
 from .SE_UNet import CATConv, DropLayer, SE_UNet, SSEConv, SSEConv2, get_model
 from .optim import AdamW
+from .postprocess import double_threshold_iteration, postprocess_prediction, zero_borders
 from .losses import atr_loss, dice_loss, fused_logit_loss, fused_stage_loss, general_union_loss_lib
 from .sliding_window import sliding_window_predict, two_channel, window_starts
 
 __all__ = ["SE_UNet", "SSEConv", "SSEConv2", "CATConv", "DropLayer", "get_model", "dice_loss",
            "general_union_loss_lib", "atr_loss", "fused_logit_loss", "fused_stage_loss",
-           "sliding_window_predict", "two_channel", "window_starts", "AdamW"]
+           "sliding_window_predict", "two_channel", "window_starts", "AdamW", "double_threshold_iteration", "postprocess_prediction", "zero_borders"]

@@ -175,6 +175,15 @@ int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, 
   return launch_loss_grad(pred, apply_sigmoid, target, weight, skel, n, sums, c_dice, c_gul, c_atr, g_scale, g_scale_dev, g_pred, S(s));
 }
 
+size_t seunet_dti_workspace_bytes(int h, int w, int z) {
+  if (h < 1 || w < 1 || z < 1) { fail("dti_workspace_bytes: bad dimensions"); return 0; }
+  return dti_workspace_bytes(h, w, z);
+}
+int seunet_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out,
+               void* workspace, size_t workspace_bytes, seunet_stream_t s) {
+  return launch_dti(pred, h, w, z, h_thresh, l_thresh, out, workspace, workspace_bytes, S(s));
+}
+
 int seunet_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                       const long long* counts, int n_tensors, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, int maximize, seunet_stream_t s) {

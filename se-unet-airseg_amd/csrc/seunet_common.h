@@ -240,6 +240,9 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, 
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate,
                          Dims din, hipStream_t s);
 int launch_multi_zero(float* const* ptrs, const int* counts, int n, hipStream_t s);
+size_t dti_workspace_bytes(int h, int w, int z);
+int launch_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out,
+               void* workspace, size_t ws_bytes, hipStream_t s);
 int launch_adamw(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const long long* counts, int n, double lr, double beta1, double beta2, double eps, double weight_decay,
                  int step, int maximize, hipStream_t s);

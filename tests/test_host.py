@@ -147,3 +147,14 @@ def test_adamw_surface_and_no_cpu_path():
     p.grad = torch.ones(4)
     with pytest.raises(RuntimeError):     # no CPU fallback: either the library is missing or the tensor is not on the GPU
         opt.step()
+
+
+def test_postprocess_surface_and_no_cpu_path():
+    import numpy as np
+    import seunet_amd as A
+    v = np.zeros((20, 20, 4)); v[:] = 1.0
+    out = A.zero_borders(v.copy())                      # prediction.py:111-114 literals
+    assert out[:3].sum() == 0 and out[17:].sum() == 0 and out[:, :3].sum() == 0 and out[:, 17:].sum() == 0
+    assert out[3:17, 3:17].min() == 1.0
+    with pytest.raises(RuntimeError):                   # CPU tensor: refused, there is no CPU implementation
+        A.double_threshold_iteration(torch.zeros(2, 2, 2), 0.5, 0.4)

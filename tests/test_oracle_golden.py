@@ -148,3 +148,20 @@ def test_adamw_oracle_matches_torch_adamw_fixture(golden_dir):
         for k in ("exp_avg", "exp_avg_sq"):
             ref = d[f"{k}_{i}"]
             np.testing.assert_allclose(res[k][i], ref, rtol=1e-6, atol=2e-7 * float(np.abs(ref).max()))
+
+
+def test_dti_oracle_matches_reference_function_fixture(golden_dir):
+    """oracle/dti_oracle.c against outputs of the reference's own double_threshold_iteration (oracle/make_golden_dti.py)."""
+    import dti_oracle as do
+    d = _load(golden_dir, "dti_known.npz")
+    assert int(d["n"]) >= 6
+    for c in range(int(d["n"])):
+        got = do.double_threshold_iteration(d[f"pred_{c}"], float(d[f"h_{c}"]), float(d[f"l_{c}"]))
+        assert got.dtype == np.float64 and set(np.unique(got)) <= {0.0, 1.0}
+        np.testing.assert_array_equal(got.astype(np.uint8), d[f"out_{c}"])
+    # the sweep is order dependent (SURVEY Q11): a weak chain fed from its far end along k stays off except next to the seed
+    chain = np.zeros((3, 3, 10)); chain[1, 1, :] = 0.45; chain[1, 1, 9] = 0.9
+    out = do.double_threshold_iteration(chain, 0.5, 0.4)
+    assert out[1, 1].tolist() == [0, 0, 0, 0, 0, 0, 0, 0, 1, 1]
+    chain[1, 1, 9] = 0.45; chain[1, 1, 0] = 0.9          # fed from the near end: the whole chain switches on
+    assert do.double_threshold_iteration(chain, 0.5, 0.4)[1, 1].sum() == 10
