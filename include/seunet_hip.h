@@ -96,6 +96,18 @@ int seunet_cat_epilogue_bwd(int dtype, const void* g_out, const void* raw, const
                             const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, void* dx2,
                             double* stat_partial, double* stat_partial2, seunet_dims dims, seunet_stream_t s);
 
+/* pass B of a two-branch block whose second branch is the 1x1x1 conv of the <= 2-channel network input (x33 / x63 / x93,
+ * SE_UNet.py:112,118,124): the weight gradient of that conv is accumulated in the same pass (dW2[c][i] = sum draw2[c]*x[i])
+ * instead of storing draw2 for a separate weight-gradient launch.  x_in: the packed 8-channel input [N][D][H][W][8] of
+ * the level; xw_partial: seunet_cat_xgrad_records(dims) * c * 2 floats; seunet_cat_xgrad_reduce then writes
+ * dw (c, in_channel, 1, 1, 1). */
+int seunet_cat_xgrad_records(seunet_dims dims);
+int seunet_cat_epilogue_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                                  const void* raw2, const float* mean2, const float* rstd2, int c, float slope,
+                                  const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx,
+                                  const void* x_in, float* xw_partial, seunet_dims dims, seunet_stream_t s);
+int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_channel, float* dw, seunet_stream_t s);
+
 /* ---- nn.MaxPool3d(2,2) SE_UNet.py:131-133 ; nn.Upsample(x2 trilinear align_corners) :136-138 ---------- */
 int seunet_maxpool_fwd(int dtype, const void* in, int c, void* out, seunet_dims in_dims, seunet_stream_t s);
 int seunet_maxpool_bwd(int dtype, const void* in, const void* g_out, int c, void* g_in, int accumulate,

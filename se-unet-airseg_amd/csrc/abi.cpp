@@ -175,6 +175,19 @@ int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, 
   return launch_loss_grad(pred, apply_sigmoid, target, weight, skel, n, sums, c_dice, c_gul, c_atr, g_scale, g_scale_dev, g_pred, S(s));
 }
 
+int seunet_cat_xgrad_records(seunet_dims dims) { return cat_xgrad_records(D(dims)); }
+int seunet_cat_epilogue_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                                  const void* raw2, const float* mean2, const float* rstd2, int c, float slope,
+                                  const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx,
+                                  const void* x_in, float* xw_partial, seunet_dims dims, seunet_stream_t s) {
+  return launch_cat_bwd_xgrad(dtype, g_out, raw, mean, rstd, raw2, mean2, rstd2, c, slope, m1, m2, m1b, m2b, dx, x_in,
+                              xw_partial, D(dims), S(s));
+}
+int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_channel, float* dw, seunet_stream_t s) {
+  SEUNET_CHECK(xw_partial && dw && records >= 1 && c >= 8, "cat_xgrad_reduce: bad argument");
+  return launch_cat_xgrad_reduce(xw_partial, records, c, in_channel, dw, S(s));
+}
+
 size_t seunet_dti_workspace_bytes(int h, int w, int z) {
   if (h < 1 || w < 1 || z < 1) { fail("dti_workspace_bytes: bad dimensions"); return 0; }
   return dti_workspace_bytes(h, w, z);

@@ -47,6 +47,19 @@ void prof_mark(const char* tag, hipStream_t s) {
   p.marks.emplace_back(tag, p.used);
   ++p.used;
 }
+// hipFuncSetAttribute is per device: each kernel instantiation keeps a bit mask of the devices it was configured on
+// (one process per GPU is the normal case; a process driving several devices, e.g. nn.DataParallel, still works)
+bool first_use_on_device(unsigned long long& mask) {
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  std::lock_guard<std::mutex> lock(mu);
+  const unsigned long long bit = 1ull << dev;
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 // ---- a per-device page of zeros: source of padding voxels / channels for the weight-gradient LDS-DMA -------------
 // (one hipMalloc + hipMemset per device for the life of the process, instead of a fill kernel in every launch)
 const void* device_zero_page() {

@@ -447,7 +447,10 @@ cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
 
 // APPLY = false: per-(n,c) f64 sums of dxhat, dxhat*xhat for one or two branches (nothing stored)
 // APPLY = true : draw = rstd * (dxhat - m1 - xhat * m2) for each branch (dxhat_out may alias g_out)
-template <typename T, int LPV, bool TWO, bool APPLY>
+// XW (pass B of a two-branch block whose second branch is a 1x1x1 conv of the <= 2-channel network input, the x33 / x63 /
+//     x93 detail-injection convs): instead of storing draw2 for a separate weight-gradient launch, accumulate that
+//     gradient here, dW2[c][i] = sum_v draw2[v][c] * x[v][i], into one record per block (summed by xw_reduce_kernel)
+template <typename T, int LPV, bool TWO, bool APPLY, bool XW = false>
 __global__ void __launch_bounds__(EPI_THREADS)
 cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
                const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -456,13 +459,17 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
                const float* __restrict__ m1p, const float* __restrict__ m2p,
                const float* __restrict__ m1bp, const float* __restrict__ m2bp, T* dxhat_out,
                T* dxhat2_out, double* __restrict__ stat_partial,
-               double* __restrict__ stat_partial2, long long V) {
+               double* __restrict__ stat_partial2, long long V,
+               const T* __restrict__ xin = nullptr, float* __restrict__ xw_partial = nullptr) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
   constexpr int VPB = EPI_THREADS / LPV;
   const int c0 = cg * 8;
   float mu[8], rs[8], mu2[8], rs2[8], a1[8], a2[8], b1[8], b2[8];
   double s[4][8];
+  float xw[8][2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xw[j][0] = xw[j][1] = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
@@ -511,9 +518,32 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
         if (APPLY) d2[j] = rs2[j] * (d2[j] - b1[j] - xh * b2[j]);
         else { s[2][j] += (double)d2[j]; s[3][j] += (double)d2[j] * (double)xh; }
       }
-      if (APPLY) store8(dxhat2_out + o, d2);
+      if (APPLY && !XW) store8(dxhat2_out + o, d2);
+      if (XW) {
+        float xi[8];
+        load8(xin + ((long long)n * V + v) * 8, xi);   // the packed 8-channel input voxel (16 / 32 B, shared by the LPV lanes)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xw[j][0] += d2[j] * xi[0]; xw[j][1] += d2[j] * xi[1]; }
+      }
     }
     if (APPLY) store8(dxhat_out + o, d);  // may alias g_out (same element, read before write)
+  }
+  if (XW) {   // block record [C][2], fixed-order sums
+    __shared__ float redx[4][16][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float r = stride_sum<LPV>(xw[j][i]);
+        if (lane < LPV) redx[wave][lane][j * 2 + i] = r;
+      }
+    __syncthreads();
+    float* rec = xw_partial + ((long long)n * P + blockIdx.x) * (C * 2);
+    for (int e = threadIdx.x; e < LPV * 16; e += EPI_THREADS) {
+      const int gq = e / 16, k = e % 16;
+      rec[(gq * 8 + (k >> 1)) * 2 + (k & 1)] = ((redx[0][gq][k] + redx[1][gq][k]) + redx[2][gq][k]) + redx[3][gq][k];
+    }
   }
   if (APPLY) return;
   __shared__ double red[4][16][32];
@@ -627,6 +657,47 @@ int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* d
                         float* dw_side, float* db_side, float* dhead_w, hipStream_t s) {
   pgrad_reduce_kernel<<<cdiv(4 * C + 4, 4), 256, 0, s>>>(pgrad_partial, records, C, dw_se, dw_se2,
                                                         dw_side, db_side, dhead_w);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// dW2 (PyTorch layout (C, in_channel, 1, 1, 1)) = f64 fixed-order sum of the XW block records; one wave per (c, i)
+__global__ void __launch_bounds__(256)
+xw_reduce_kernel(const float* __restrict__ part, int records, int C, int in_channel, float* __restrict__ dw) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + wave;          // k = c * 2 + i
+  if (k >= C * 2) return;
+  double s = 0.0;
+  for (int r = lane; r < records; r += 64) s += (double)part[(long long)r * (C * 2) + k];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  const int c = k >> 1, i = k & 1;
+  if (lane == 0 && i < in_channel) dw[c * in_channel + i] = (float)s;
+}
+
+int cat_xgrad_records(Dims d) { return d.N * epi_partials(d) * 4; }
+
+int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_channel, float* dw, hipStream_t s) {
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_xgrad_reduce: in_channel %d (1 or 2)", in_channel);
+  xw_reduce_kernel<<<cdiv(C * 2, 4), 256, 0, s>>>(xw_partial, records, C, in_channel, dw);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// pass B of a two-branch aggregation block with the x-branch weight gradient fused in (see cat_bwd_kernel, XW)
+int launch_cat_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                         const void* raw2, const float* mean2, const float* rstd2, int C, float slope, const float* m1,
+                         const float* m2, const float* m1b, const float* m2b, void* dx, const void* x_in,
+                         float* xw_partial, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  SEUNET_CHECK(g_out && raw && raw2 && m1 && m2 && m1b && m2b && dx && x_in && xw_partial, "cat_epilogue_bwd_xgrad: null argument");
+  dim3 grid(epi_partials(d) * 4, d.N);
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16)
+      cat_bwd_kernel<bf16_t, LPV, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (bf16_t*)dx, nullptr, nullptr, nullptr, d.vox(), (const bf16_t*)x_in, xw_partial);
+    else
+      cat_bwd_kernel<float, LPV, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (float*)dx, nullptr, nullptr, nullptr, d.vox(), (const float*)x_in, xw_partial);
+  });
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

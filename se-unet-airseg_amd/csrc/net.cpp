@@ -139,7 +139,7 @@ struct Plan {
   size_t feat[T_COUNT], grad[T_COUNT];
   OpRes op[kNumOps];
   size_t lvl[2][4], glvl[2][4];
-  size_t stats, stats2, pgrad, m1, m2, m1b, m2b, wgrad_ws, head_tmp, gx;
+  size_t stats, stats2, pgrad, m1, m2, m1b, m2b, wgrad_ws, head_tmp, gx, gx_bytes = 0;
   size_t wgrad_ws_bytes;
   size_t total;
   int stat_slots_max;
@@ -214,6 +214,7 @@ struct Plan {
     wgrad_ws = take(wg_max);
     head_tmp = take(head_bwd_tmp_floats(dims[0]) * 4);
     gx = take(gx_max);
+    gx_bytes = gx_max;
     total = cur;
     return 0;
   }
@@ -478,13 +479,24 @@ struct Exec {
         if (o.xname)
           if (int e = launch_stats_finalize(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
         mark("in_bwd:" + n);    // pass B
-        if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
-                                   p.d.negative_slope, fat(p.m1), fat(p.m2), o.xname ? fat(p.m1b) : nullptr,
-                                   o.xname ? fat(p.m2b) : nullptr, at(p.grad[o.dst]), o.xname ? at(p.gx) : nullptr, nullptr, nullptr,
-                                   dm, s)) return e;
-        if (o.xname) {
-          const int xi = find_param(reg, std::string(o.xname) + ".conv1.weight");
-          if (grads[xi]) {
+        const int xi = o.xname ? find_param(reg, std::string(o.xname) + ".conv1.weight") : -1;
+        // x-branch (x33 / x63 / x93: a 1x1x1 conv of the <= 2-channel input): its weight gradient is accumulated inside
+        // pass B instead of storing draw2 (C channels per voxel) for a separate weight-gradient launch
+        const bool fuse_x = o.xname && grads[xi] && p.d.in_channel <= 2 && p.d.conv_impl != SEUNET_CONV_NAIVE &&
+                            (size_t)cat_xgrad_records(dm) * r.cout * 2 * sizeof(float) <= p.gx_bytes;
+        if (fuse_x) {
+          float* xwp = reinterpret_cast<float*>(at(p.gx));
+          if (int e = launch_cat_bwd_xgrad(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
+                                           p.d.negative_slope, fat(p.m1), fat(p.m2), fat(p.m1b), fat(p.m2b), at(p.grad[o.dst]),
+                                           at(p.feat[o.xsrc]), xwp, dm, s)) return e;
+          mark("stats");
+          if (int e = launch_cat_xgrad_reduce(xwp, cat_xgrad_records(dm), r.cout, p.d.in_channel, grads[xi], s)) return e;
+        } else {
+          if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
+                                     p.d.negative_slope, fat(p.m1), fat(p.m2), o.xname ? fat(p.m1b) : nullptr,
+                                     o.xname ? fat(p.m2b) : nullptr, at(p.grad[o.dst]), o.xname ? at(p.gx) : nullptr, nullptr, nullptr,
+                                     dm, s)) return e;
+          if (o.xname && grads[xi]) {
             mark(std::string("wgrad:") + o.xname);
             SrcList xs{};
             xs.n = 1; xs.ptr[0] = at(p.feat[o.xsrc]); xs.C[0] = 8;

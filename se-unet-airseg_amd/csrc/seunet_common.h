@@ -233,6 +233,12 @@ int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* m
                    double* stat_partial2, Dims d, hipStream_t s);
 
 // pooling / interpolation / heads (resample.hip)
+int cat_xgrad_records(Dims d);
+int launch_cat_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                         const void* raw2, const float* mean2, const float* rstd2, int C, float slope, const float* m1,
+                         const float* m2, const float* m1b, const float* m2b, void* dx, const void* x_in,
+                         float* xw_partial, Dims d, hipStream_t s);
+int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_channel, float* dw, hipStream_t s);
 int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);
 int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void* g_in,
                        int accumulate, Dims din, hipStream_t s);
@@ -246,6 +252,7 @@ int launch_dti(const double* pred, int h, int w, int z, double h_thresh, double 
 int launch_adamw(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const long long* counts, int n, double lr, double beta1, double beta2, double eps, double weight_decay,
                  int step, int maximize, hipStream_t s);
+bool first_use_on_device(unsigned long long& mask);   // true once per (kernel instantiation, device): raises its LDS limit then
 const void* device_zero_page();   // >= 256 zero bytes on the current device (allocated once per device, never freed)
 int launch_side_upsample(const float* side, int C, int scale, float* out_ncdhw, int c_total,
                          int c_off, Dims dlow, hipStream_t s);

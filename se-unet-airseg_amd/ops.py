@@ -210,6 +210,32 @@ def cat_epilogue_bwd(g_out, raw, mean, rstd, raw2=None, mean2=None, rstd2=None, 
     return dx, dx2
 
 
+def cat_epilogue_bwd_xgrad(g_out, raw, mean, rstd, raw2, mean2, rstd2, x_in, in_channel, slope=0.01):
+    """Two-branch backward with the x-branch weight gradient fused into pass B (``seunet_cat_epilogue_bwd_xgrad``).
+    x_in: packed 8-channel input [N, D, H, W, 8].  Returns (dx, dW2 of shape (C, in_channel, 1, 1, 1))."""
+    lib = _lib.load()
+    n, d, h, w, c = raw.shape
+    dims = _dims_cl(raw)
+    slots = lib.seunet_epilogue_slots(dims)
+    st = torch.zeros((n, slots, c, 2), dtype=torch.float64, device=raw.device)
+    st2 = torch.zeros_like(st)
+    _lib.check(lib.seunet_cat_epilogue_bwd(_code(raw), g_out.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           raw2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), c, slope, None, None, None, None,
+                                           None, None, st.data_ptr(), st2.data_ptr(), dims, _s()), "cat_epilogue_bwd (pass A)")
+    m1, m2 = stats_finalize(st, slots, d * h * w, 0.0, 1)
+    m1b, m2b = stats_finalize(st2, slots, d * h * w, 0.0, 1)
+    records = lib.seunet_cat_xgrad_records(dims)
+    part = torch.empty((records, c, 2), dtype=torch.float32, device=raw.device)
+    dx = torch.empty_like(raw)
+    _lib.check(lib.seunet_cat_epilogue_bwd_xgrad(_code(raw), g_out.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                 raw2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), c, slope, m1.data_ptr(),
+                                                 m2.data_ptr(), m1b.data_ptr(), m2b.data_ptr(), dx.data_ptr(), x_in.data_ptr(),
+                                                 part.data_ptr(), dims, _s()), "cat_epilogue_bwd_xgrad")
+    dw = torch.zeros((c, in_channel, 1, 1, 1), dtype=torch.float32, device=raw.device)
+    _lib.check(lib.seunet_cat_xgrad_reduce(part.data_ptr(), records, c, in_channel, dw.data_ptr(), _s()), "cat_xgrad_reduce")
+    return dx, dw
+
+
 # ---- pooling / interpolation / heads ---------------------------------------------------------------------
 def maxpool_fwd(t):
     n, d, h, w, c = t.shape
