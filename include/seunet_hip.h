@@ -96,16 +96,27 @@ int seunet_cat_epilogue_bwd(int dtype, const void* g_out, const void* raw, const
                             const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, void* dx2,
                             double* stat_partial, double* stat_partial2, seunet_dims dims, seunet_stream_t s);
 
-/* pass B of a two-branch block whose second branch is the 1x1x1 conv of the <= 2-channel network input (x33 / x63 / x93,
- * SE_UNet.py:112,118,124): the weight gradient of that conv is accumulated in the same pass (dW2[c][i] = sum draw2[c]*x[i])
- * instead of storing draw2 for a separate weight-gradient launch.  x_in: the packed 8-channel input [N][D][H][W][8] of
- * the level; xw_partial: seunet_cat_xgrad_records(dims) * c * 2 floats; seunet_cat_xgrad_reduce then writes
- * dw (c, in_channel, 1, 1, 1). */
+/* Two-branch block whose second branch is the 1x1x1 conv of the <= 2-channel network input (x33 / x63 / x93,
+ * SE_UNet.py:112,118,124,187,196,205).  That conv's output is never materialised: every pass recomputes
+ * raw2[c] = w2[c][0]*x0 + w2[c][1]*x1 from x_in, the packed 8-channel input [N][D][H][W][8] of the level (16 B per voxel
+ * instead of 2*c); its InstanceNorm statistics follow from the input's second moments (seunet_xbranch_moments ->
+ * seunet_xbranch_stats, exact in f64); and pass B of the backward accumulates the conv's weight gradient
+ * dW2[c][i] = sum draw2[c]*x[i] itself (one record per block in xw_partial: seunet_cat_xgrad_records(dims) * c * 2
+ * floats), which seunet_cat_xgrad_reduce sums into dw (c, in_channel, 1, 1, 1).  w2: (c, in_channel) f32. */
+int seunet_xbranch_moment_slots(seunet_dims dims);
+int seunet_xbranch_moments(int dtype, const void* x_in, double* partial /* [n][slots][5] */, seunet_dims dims, seunet_stream_t s);
+int seunet_xbranch_stats(const double* partial, int slots, const float* w2, int c, int in_channel, int n, long long count,
+                         float eps, float* mean2, float* rstd2, seunet_stream_t s);
+int seunet_cat_epilogue_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in,
+                              const float* w2, int in_channel, const float* mean2, const float* rstd2, int c, float slope,
+                              void* out, seunet_dims dims, seunet_stream_t s);
+/* pass A (m1 == NULL): f64 partials of both branches; pass B: dx (may alias g_out) + xw_partial */
+int seunet_cat_epilogue_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                              const void* x_in, const float* w2, int in_channel, const float* mean2, const float* rstd2,
+                              int c, float slope, const float* m1, const float* m2, const float* m1b, const float* m2b,
+                              void* dx, double* stat_partial, double* stat_partial2, float* xw_partial, seunet_dims dims,
+                              seunet_stream_t s);
 int seunet_cat_xgrad_records(seunet_dims dims);
-int seunet_cat_epilogue_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
-                                  const void* raw2, const float* mean2, const float* rstd2, int c, float slope,
-                                  const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx,
-                                  const void* x_in, float* xw_partial, seunet_dims dims, seunet_stream_t s);
 int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_channel, float* dw, seunet_stream_t s);
 
 /* ---- nn.MaxPool3d(2,2) SE_UNet.py:131-133 ; nn.Upsample(x2 trilinear align_corners) :136-138 ---------- */

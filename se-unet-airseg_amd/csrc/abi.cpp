@@ -176,12 +176,30 @@ int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, 
 }
 
 int seunet_cat_xgrad_records(seunet_dims dims) { return cat_xgrad_records(D(dims)); }
-int seunet_cat_epilogue_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
-                                  const void* raw2, const float* mean2, const float* rstd2, int c, float slope,
-                                  const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx,
-                                  const void* x_in, float* xw_partial, seunet_dims dims, seunet_stream_t s) {
-  return launch_cat_bwd_xgrad(dtype, g_out, raw, mean, rstd, raw2, mean2, rstd2, c, slope, m1, m2, m1b, m2b, dx, x_in,
-                              xw_partial, D(dims), S(s));
+int seunet_xbranch_moment_slots(seunet_dims dims) { return xbranch_moment_slots(D(dims)); }
+int seunet_xbranch_moments(int dtype, const void* x_in, double* partial, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(x_in && partial, "xbranch_moments: null argument");
+  return launch_xbranch_moments(dtype, x_in, partial, D(dims), S(s));
+}
+int seunet_xbranch_stats(const double* partial, int slots, const float* w2, int c, int in_channel, int n, long long count,
+                         float eps, float* mean2, float* rstd2, seunet_stream_t s) {
+  SEUNET_CHECK(partial && w2 && mean2 && rstd2 && slots >= 1 && c >= 1 && n >= 1 && count >= 1, "xbranch_stats: bad argument");
+  return launch_xbranch_stats(partial, slots, w2, c, in_channel, n, count, eps, mean2, rstd2, S(s));
+}
+int seunet_cat_epilogue_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in,
+                              const float* w2, int in_channel, const float* mean2, const float* rstd2, int c, float slope,
+                              void* out, seunet_dims dims, seunet_stream_t s) {
+  SEUNET_CHECK(raw && mean && rstd && x_in && w2 && mean2 && rstd2 && out, "cat_epilogue_fwd_x: null argument");
+  return launch_cat_fwd_x(dtype, raw, mean, rstd, x_in, w2, in_channel, mean2, rstd2, c, slope, out, D(dims), S(s));
+}
+int seunet_cat_epilogue_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
+                              const void* x_in, const float* w2, int in_channel, const float* mean2, const float* rstd2,
+                              int c, float slope, const float* m1, const float* m2, const float* m1b, const float* m2b,
+                              void* dx, double* stat_partial, double* stat_partial2, float* xw_partial, seunet_dims dims,
+                              seunet_stream_t s) {
+  SEUNET_CHECK(g_out && raw && mean && rstd && x_in && w2 && mean2 && rstd2, "cat_epilogue_bwd_x: null argument");
+  return launch_cat_bwd_x(dtype, g_out, raw, mean, rstd, x_in, w2, in_channel, mean2, rstd2, c, slope, m1, m2, m1b, m2b, dx,
+                          stat_partial, stat_partial2, xw_partial, D(dims), S(s));
 }
 int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_channel, float* dw, seunet_stream_t s) {
   SEUNET_CHECK(xw_partial && dw && records >= 1 && c >= 8, "cat_xgrad_reduce: bad argument");

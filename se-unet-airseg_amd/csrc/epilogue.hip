@@ -390,24 +390,101 @@ pgrad_reduce_kernel(const float* __restrict__ pg, int records, int C, float* dw_
 }
 
 // ----------------------------------------------------------------------------------
+// x-branch statistics without the x-branch tensor.  raw2 = W2 x is linear in the (<= 2-channel) input, so its per-(n,c)
+// InstanceNorm statistics follow from the input's first and second moments per sample:
+//     mean2[c] = sum_i W2[c][i] m_i,      var2[c] = sum_ij W2[c][i] W2[c][j] (M_ij - m_i m_j)        (f64)
+// ----------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(EPI_THREADS)
+input_moments_kernel(const T* __restrict__ xin, double* __restrict__ partial, long long V) {
+  const int n = blockIdx.y, P = gridDim.x;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // x0, x1, x0^2, x0 x1, x1^2
+  for (long long v = (long long)blockIdx.x * EPI_THREADS + threadIdx.x; v < V; v += (long long)P * EPI_THREADS) {
+    float x[8];
+    load8(xin + ((long long)n * V + v) * 8, x);
+    const double a = (double)x[0], b = (double)x[1];
+    s[0] += a; s[1] += b; s[2] += a * a; s[3] += a * b; s[4] += b * b;
+  }
+  __shared__ double red[4][5];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double r = s[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+    if (lane == 0) red[wave][k] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int k = threadIdx.x;
+    partial[((long long)n * P + blockIdx.x) * 5 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+  }
+}
+
+// one 256-thread block per sample: fixed-order sum of the moment partials, then mean / rstd of every output channel
+__global__ void __launch_bounds__(256)
+xbranch_stats_kernel(const double* __restrict__ partial, int slots, const float* __restrict__ w2, int C, int ic,
+                     double inv_count, float eps, float* __restrict__ mean2, float* __restrict__ rstd2) {
+  const int n = blockIdx.x;
+  __shared__ double red[4][5], tot[5];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < slots; b += 256)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] += partial[((long long)n * slots + b) * 5 + k];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double r = s[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+    if (lane == 0) red[wave][k] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) tot[threadIdx.x] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * inv_count;
+  __syncthreads();
+  const double m0 = tot[0], m1 = tot[1];
+  const double c00 = tot[2] - m0 * m0, c01 = tot[3] - m0 * m1, c11 = tot[4] - m1 * m1;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double a = (double)w2[c * ic], b = ic > 1 ? (double)w2[c * ic + 1] : 0.0;
+    const double mu = a * m0 + b * m1;
+    double var = a * a * c00 + 2.0 * a * b * c01 + b * b * c11;
+    if (var < 0.0) var = 0.0;
+    mean2[n * C + c] = (float)mu;
+    rstd2[n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// ----------------------------------------------------------------------------------
 // aggregation block (1x1x1 conv output -> IN -> LeakyReLU, optional second branch added)
 // ----------------------------------------------------------------------------------
-template <typename T, int LPV, bool TWO>
+// XR (x-branch recompute): the second branch is the 1x1x1 conv of the <= 2-channel network input (x33 / x63 / x93,
+//     SE_UNet.py:112,118,124).  Its raw output is never stored: `raw2` then points at the packed 8-channel INPUT
+//     [N][V][8] and raw2[c] = w2x[c][0]*x0 + w2x[c][1]*x1 is recomputed per voxel (16 B read instead of 2C bytes);
+//     its InstanceNorm statistics come from the input's second moments (xbranch_stats_kernel).
+template <bool XR>
+__device__ __forceinline__ void second_branch(const float (&in8)[8], const float (&wa)[8], const float (&wb)[8], float (&x2)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x2[j] = XR ? wa[j] * in8[0] + wb[j] * in8[1] : in8[j];
+}
+
+template <typename T, int LPV, bool TWO, bool XR = false>
 __global__ void __launch_bounds__(EPI_THREADS)
 cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
                const float* __restrict__ rstd, const T* __restrict__ raw2,
                const float* __restrict__ mean2, const float* __restrict__ rstd2, int C, float slope,
-               T* __restrict__ out, long long V) {
+               T* __restrict__ out, long long V, const float* __restrict__ w2x = nullptr, int xic = 0) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
   constexpr int VPB = EPI_THREADS / LPV;
   const int c0 = cg * 8;
-  float mu[8], rs[8], mu2[8], rs2[8];
+  float mu[8], rs[8], mu2[8], rs2[8], wa[8], wb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
     mu2[j] = TWO ? mean2[n * C + c0 + j] : 0.f;
     rs2[j] = TWO ? rstd2[n * C + c0 + j] : 0.f;
+    wa[j] = XR ? w2x[(c0 + j) * xic] : 0.f;
+    wb[j] = (XR && xic > 1) ? w2x[(c0 + j) * xic + 1] : 0.f;
   }
   const long long stride = (long long)P * VPB;
   long long v = (long long)blockIdx.x * VPB + vb;
@@ -416,16 +493,16 @@ cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   if (v < V) {
     const long long o = ((long long)n * V + v) * C + c0;
     load8p(raw + o, nx);
-    if (TWO) load8p(raw2 + o, nx2);
+    if (TWO) load8p(XR ? raw2 + ((long long)n * V + v) * 8 : raw2 + o, nx2);
   }
   for (; v < V; v += stride) {
     const long long o = ((long long)n * V + v) * C + c0;
-    float x[8], x2[8], y[8];
+    float x[8], in2[8], x2[8], y[8];
     unpack8(nx, x);
-    if (TWO) unpack8(nx2, x2);
+    if (TWO) { unpack8(nx2, in2); second_branch<XR>(in2, wa, wb, x2); }
     if (v + stride < V) {
       load8p(raw + o + stride * C, nx);
-      if (TWO) load8p(raw2 + o + stride * C, nx2);
+      if (TWO) load8p(XR ? raw2 + ((long long)n * V + v + stride) * 8 : raw2 + o + stride * C, nx2);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -450,7 +527,7 @@ cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
 // XW (pass B of a two-branch block whose second branch is a 1x1x1 conv of the <= 2-channel network input, the x33 / x63 /
 //     x93 detail-injection convs): instead of storing draw2 for a separate weight-gradient launch, accumulate that
 //     gradient here, dW2[c][i] = sum_v draw2[v][c] * x[v][i], into one record per block (summed by xw_reduce_kernel)
-template <typename T, int LPV, bool TWO, bool APPLY, bool XW = false>
+template <typename T, int LPV, bool TWO, bool APPLY, bool XW = false, bool XR = false>
 __global__ void __launch_bounds__(EPI_THREADS)
 cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
                const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -460,16 +537,21 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
                const float* __restrict__ m1bp, const float* __restrict__ m2bp, T* dxhat_out,
                T* dxhat2_out, double* __restrict__ stat_partial,
                double* __restrict__ stat_partial2, long long V,
-               const T* __restrict__ xin = nullptr, float* __restrict__ xw_partial = nullptr) {
+               const T* __restrict__ xin = nullptr, float* __restrict__ xw_partial = nullptr,
+               const float* __restrict__ w2x = nullptr, int xic = 0) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
   constexpr int VPB = EPI_THREADS / LPV;
   const int c0 = cg * 8;
   float mu[8], rs[8], mu2[8], rs2[8], a1[8], a2[8], b1[8], b2[8];
   double s[4][8];
-  float xw[8][2];
+  float xw[8][2], wa[8], wb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) xw[j][0] = xw[j][1] = 0.f;
+  for (int j = 0; j < 8; ++j) {
+    xw[j][0] = xw[j][1] = 0.f;
+    wa[j] = XR ? w2x[(c0 + j) * xic] : 0.f;
+    wb[j] = (XR && xic > 1) ? w2x[(c0 + j) * xic + 1] : 0.f;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
@@ -489,18 +571,18 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
     const long long o = ((long long)n * V + v) * C + c0;
     load8p(g_out + o, ng);
     load8p(raw + o, nx);
-    if (TWO) load8p(raw2 + o, nx2);
+    if (TWO) load8p(XR ? raw2 + ((long long)n * V + v) * 8 : raw2 + o, nx2);
   }
   for (; v < V; v += stride) {
     const long long o = ((long long)n * V + v) * C + c0;
-    float gy[8], x[8], x2[8], d[8];
+    float gy[8], x[8], in2[8], x2[8], d[8];
     unpack8(ng, gy);
     unpack8(nx, x);
-    if (TWO) unpack8(nx2, x2);
+    if (TWO) { unpack8(nx2, in2); second_branch<XR>(in2, wa, wb, x2); }
     if (v + stride < V) {   // a later voxel of this same thread: never written by anyone before it is read
       load8p(g_out + o + stride * C, ng);
       load8p(raw + o + stride * C, nx);
-      if (TWO) load8p(raw2 + o + stride * C, nx2);
+      if (TWO) load8p(XR ? raw2 + ((long long)n * V + v + stride) * 8 : raw2 + o + stride * C, nx2);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -521,7 +603,12 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
       if (APPLY && !XW) store8(dxhat2_out + o, d2);
       if (XW) {
         float xi[8];
-        load8(xin + ((long long)n * V + v) * 8, xi);   // the packed 8-channel input voxel (16 / 32 B, shared by the LPV lanes)
+        if (XR) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xi[j] = in2[j];
+        } else {
+          load8(xin + ((long long)n * V + v) * 8, xi);   // the packed 8-channel input voxel (16 / 32 B, shared by the LPV lanes)
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { xw[j][0] += d2[j] * xi[0]; xw[j][1] += d2[j] * xi[1]; }
       }
@@ -684,19 +771,61 @@ int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_
   return 0;
 }
 
-// pass B of a two-branch aggregation block with the x-branch weight gradient fused in (see cat_bwd_kernel, XW)
-int launch_cat_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
-                         const void* raw2, const float* mean2, const float* rstd2, int C, float slope, const float* m1,
-                         const float* m2, const float* m1b, const float* m2b, void* dx, const void* x_in,
-                         float* xw_partial, Dims d, hipStream_t s) {
+// ---- two-branch aggregation block whose second branch is recomputed from the network input (XR) ---------------------
+int xbranch_moment_slots(Dims d) { return epi_partials(d); }
+
+int launch_xbranch_moments(int dtype, const void* x_in, double* partial, Dims d, hipStream_t s) {
+  dim3 grid(xbranch_moment_slots(d), d.N);
+  if (dtype == SEUNET_BF16) input_moments_kernel<bf16_t><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)x_in, partial, d.vox());
+  else input_moments_kernel<float><<<grid, EPI_THREADS, 0, s>>>((const float*)x_in, partial, d.vox());
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_xbranch_stats(const double* partial, int slots, const float* w2, int C, int in_channel, int N, long long count,
+                         float eps, float* mean2, float* rstd2, hipStream_t s) {
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "xbranch_stats: in_channel %d (1 or 2)", in_channel);
+  xbranch_stats_kernel<<<N, 256, 0, s>>>(partial, slots, w2, C, in_channel, 1.0 / (double)count, eps, mean2, rstd2);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cat_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
+                     int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, Dims d,
+                     hipStream_t s) {
   if (int e = check_c(C)) return e;
-  SEUNET_CHECK(g_out && raw && raw2 && m1 && m2 && m1b && m2b && dx && x_in && xw_partial, "cat_epilogue_bwd_xgrad: null argument");
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_epilogue_fwd_x: in_channel %d (1 or 2)", in_channel);
   dim3 grid(epi_partials(d) * 4, d.N);
   SEUNET_LPV_SWITCH(C / 8, {
     if (dtype == SEUNET_BF16)
-      cat_bwd_kernel<bf16_t, LPV, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (bf16_t*)dx, nullptr, nullptr, nullptr, d.vox(), (const bf16_t*)x_in, xw_partial);
+      cat_fwd_kernel<bf16_t, LPV, true, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, (const bf16_t*)x_in, mean2, rstd2, C, slope, (bf16_t*)out, d.vox(), w2, in_channel);
     else
-      cat_bwd_kernel<float, LPV, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (float*)dx, nullptr, nullptr, nullptr, d.vox(), (const float*)x_in, xw_partial);
+      cat_fwd_kernel<float, LPV, true, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, (const float*)x_in, mean2, rstd2, C, slope, (float*)out, d.vox(), w2, in_channel);
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// m1 == nullptr: pass A (f64 sums of both branches); otherwise pass B: writes dx (may alias g_out) and one x-branch
+// weight-gradient record per block into xw_partial (see cat_bwd_kernel XW / XR)
+int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,
+                     const float* w2, int in_channel, const float* mean2, const float* rstd2, int C, float slope,
+                     const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, double* stat_partial,
+                     double* stat_partial2, float* xw_partial, Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_epilogue_bwd_x: in_channel %d (1 or 2)", in_channel);
+  const bool apply = m1 != nullptr;
+  if (!apply) SEUNET_CHECK(stat_partial && stat_partial2, "cat_epilogue_bwd_x pass A needs the partial buffers");
+  else SEUNET_CHECK(m2 && m1b && m2b && dx && xw_partial, "cat_epilogue_bwd_x pass B: missing argument");
+  dim3 grid(epi_partials(d) * (apply ? 4 : 1), d.N);
+  SEUNET_LPV_SWITCH(C / 8, {
+    if (dtype == SEUNET_BF16) {
+      if (apply) cat_bwd_kernel<bf16_t, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (bf16_t*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel);
+      else cat_bwd_kernel<bf16_t, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel);
+    } else {
+      if (apply) cat_bwd_kernel<float, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (float*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel);
+      else cat_bwd_kernel<float, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel);
+    }
   });
   SEUNET_LAUNCH_CHECK();
   return 0;

@@ -139,7 +139,9 @@ struct Plan {
   size_t feat[T_COUNT], grad[T_COUNT];
   OpRes op[kNumOps];
   size_t lvl[2][4], glvl[2][4];
-  size_t stats, stats2, pgrad, m1, m2, m1b, m2b, wgrad_ws, head_tmp, gx, gx_bytes = 0;
+  size_t stats, stats2, pgrad, m1, m2, m1b, m2b, wgrad_ws, head_tmp, gx, gx_bytes = 0, xwp = 0, xmom = 0;
+  // x-branches (x33 / x63 / x93) recomputed from the <= 2-channel input instead of materialised (csrc/epilogue.hip, XR)
+  bool fuse_x = false;
   size_t wgrad_ws_bytes;
   size_t total;
   int stat_slots_max;
@@ -163,7 +165,8 @@ struct Plan {
       feat[t] = take(bytes);
       grad[t] = is_input(t) ? 0 : take(bytes);
     }
-    size_t gx_max = 0, wg_max = 0;
+    size_t gx_max = 0, wg_max = 0, xw_max = 0, xmom_max = 0;
+    fuse_x = d.in_channel <= 2 && d.conv_impl != SEUNET_CONV_NAIVE;
     int slots_max = 1, cmax = 8;
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
@@ -186,12 +189,17 @@ struct Plan {
       if (r.need_dgrad) r.wp_d = take(conv_wpack_bytes(d.dtype, r.taps, r.cout, r.cin));
       wg_max = std::max(wg_max, wgrad_workspace_bytes(r.taps, r.cin, r.cout));
       if (o.xname) {
-        r.raw2 = take(act);
         r.mean2 = take((size_t)d.batch * r.cout * 4);
         r.rstd2 = take((size_t)d.batch * r.cout * 4);
-        r.wp_x = take(conv_wpack_bytes(d.dtype, 1, d.in_channel, r.cout));
-        gx_max = std::max(gx_max, act);
-        wg_max = std::max(wg_max, wgrad_workspace_bytes(1, d.in_channel, r.cout));
+        if (fuse_x) {
+          xw_max = std::max(xw_max, (size_t)cat_xgrad_records(dims[lv]) * r.cout * 2 * 4);
+          xmom_max = std::max(xmom_max, (size_t)d.batch * xbranch_moment_slots(dims[lv]) * 5 * 8);
+        } else {
+          r.raw2 = take(act);
+          r.wp_x = take(conv_wpack_bytes(d.dtype, 1, d.in_channel, r.cout));
+          gx_max = std::max(gx_max, act);
+          wg_max = std::max(wg_max, wgrad_workspace_bytes(1, d.in_channel, r.cout));
+        }
       }
       slots_max = std::max(slots_max, std::max(std::max(conv_stats_tiles(dims[lv], 27, 1), conv_stats_tiles(dims[lv], 27, 2)), epi_partials(dims[lv])));
       cmax = std::max(cmax, r.cout);
@@ -215,6 +223,8 @@ struct Plan {
     head_tmp = take(head_bwd_tmp_floats(dims[0]) * 4);
     gx = take(gx_max);
     gx_bytes = gx_max;
+    xwp = take(xw_max);
+    xmom = take(xmom_max);
     total = cur;
     return 0;
   }
@@ -312,7 +322,7 @@ struct Exec {
       const std::string n = o.name;
       if (!dgrad) {
         jobs.push_back({P(n + ".conv1.weight"), at(r.wp_f), r.taps, r.cin, r.cout, 0});
-        if (o.kind == OP_CAT && o.xname) jobs.push_back({P(std::string(o.xname) + ".conv1.weight"), at(r.wp_x), 1, p.d.in_channel, r.cout, 0});
+        if (o.kind == OP_CAT && o.xname && !p.fuse_x) jobs.push_back({P(std::string(o.xname) + ".conv1.weight"), at(r.wp_x), 1, p.d.in_channel, r.cout, 0});
       } else if (r.need_dgrad) {
         jobs.push_back({P(n + ".conv1.weight"), at(r.wp_d), r.taps, r.cin, r.cout, 1});
       }
@@ -349,16 +359,28 @@ struct Exec {
         const int lv = kT[o.dst].level;
         if (int e = conv_and_stats(n, 1, 1, srcs(o), r.cin, P(n + ".conv1.weight"), nullptr, r.wp_f, r.raw, r.cout, r.mean,
                                    r.rstd, p.dims[lv])) return e;
-        if (o.xname) {
-          SrcList xs{};
-          xs.n = 1; xs.ptr[0] = at(p.feat[o.xsrc]); xs.C[0] = 8;
-          if (int e = conv_and_stats(o.xname, 1, 1, xs, p.d.in_channel, P(std::string(o.xname) + ".conv1.weight"), nullptr, r.wp_x,
-                                     r.raw2, r.cout, r.mean2, r.rstd2, p.dims[lv])) return e;
+        if (o.xname && p.fuse_x) {
+          // x-branch: statistics from the input's moments, values recomputed inside the epilogue (never stored)
+          const float* w2 = P(std::string(o.xname) + ".conv1.weight");
+          mark("stats");
+          if (int e = launch_xbranch_moments(p.d.dtype, at(p.feat[o.xsrc]), dat(p.xmom), p.dims[lv], s)) return e;
+          if (int e = launch_xbranch_stats(dat(p.xmom), xbranch_moment_slots(p.dims[lv]), w2, r.cout, p.d.in_channel, p.dims[lv].N,
+                                           p.dims[lv].vox(), p.d.eps, fat(r.mean2), fat(r.rstd2), s)) return e;
+          mark("cat_fwd:" + n);
+          if (int e = launch_cat_fwd_x(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), at(p.feat[o.xsrc]), w2, p.d.in_channel,
+                                       fat(r.mean2), fat(r.rstd2), r.cout, p.d.negative_slope, at(p.feat[o.dst]), p.dims[lv], s)) return e;
+        } else {
+          if (o.xname) {
+            SrcList xs{};
+            xs.n = 1; xs.ptr[0] = at(p.feat[o.xsrc]); xs.C[0] = 8;
+            if (int e = conv_and_stats(o.xname, 1, 1, xs, p.d.in_channel, P(std::string(o.xname) + ".conv1.weight"), nullptr, r.wp_x,
+                                       r.raw2, r.cout, r.mean2, r.rstd2, p.dims[lv])) return e;
+          }
+          mark("cat_fwd:" + n);
+          if (int e = launch_cat_fwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), o.xname ? at(r.raw2) : nullptr,
+                                     o.xname ? fat(r.mean2) : nullptr, o.xname ? fat(r.rstd2) : nullptr, r.cout,
+                                     p.d.negative_slope, at(p.feat[o.dst]), p.dims[lv], s)) return e;
         }
-        mark("cat_fwd:" + n);
-        if (int e = launch_cat_fwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), o.xname ? at(r.raw2) : nullptr,
-                                   o.xname ? fat(r.mean2) : nullptr, o.xname ? fat(r.rstd2) : nullptr, r.cout,
-                                   p.d.negative_slope, at(p.feat[o.dst]), p.dims[lv], s)) return e;
       }
     }
     const float* enc[4] = {fat(p.lvl[0][0]), fat(p.lvl[0][1]), fat(p.lvl[0][2]), fat(p.lvl[0][3])};
@@ -468,30 +490,37 @@ struct Exec {
       } else {  // OP_CAT
         SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
         mark("cat_bwd:" + n);   // pass A
-        const void* r2 = o.xname ? at(r.raw2) : nullptr;
         const float* mu2 = o.xname ? fat(r.mean2) : nullptr;
         const float* rs2 = o.xname ? fat(r.rstd2) : nullptr;
-        if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
-                                   p.d.negative_slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dat(p.stats),
-                                   dat(p.stats2), dm, s)) return e;
-        mark("stats");
-        if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
-        if (o.xname)
-          if (int e = launch_stats_finalize(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
-        mark("in_bwd:" + n);    // pass B
         const int xi = o.xname ? find_param(reg, std::string(o.xname) + ".conv1.weight") : -1;
-        // x-branch (x33 / x63 / x93: a 1x1x1 conv of the <= 2-channel input): its weight gradient is accumulated inside
-        // pass B instead of storing draw2 (C channels per voxel) for a separate weight-gradient launch
-        const bool fuse_x = o.xname && grads[xi] && p.d.in_channel <= 2 && p.d.conv_impl != SEUNET_CONV_NAIVE &&
-                            (size_t)cat_xgrad_records(dm) * r.cout * 2 * sizeof(float) <= p.gx_bytes;
-        if (fuse_x) {
-          float* xwp = reinterpret_cast<float*>(at(p.gx));
-          if (int e = launch_cat_bwd_xgrad(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
-                                           p.d.negative_slope, fat(p.m1), fat(p.m2), fat(p.m1b), fat(p.m2b), at(p.grad[o.dst]),
-                                           at(p.feat[o.xsrc]), xwp, dm, s)) return e;
+        if (o.xname && p.fuse_x) {
+          // x-branch recomputed from the input in both passes; pass B also accumulates its weight gradient
+          const float* w2 = P(std::string(o.xname) + ".conv1.weight");
+          const void* xin = at(p.feat[o.xsrc]);
+          if (int e = launch_cat_bwd_x(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), xin, w2, p.d.in_channel, mu2, rs2,
+                                       r.cout, p.d.negative_slope, nullptr, nullptr, nullptr, nullptr, nullptr, dat(p.stats), dat(p.stats2),
+                                       nullptr, dm, s)) return e;
           mark("stats");
-          if (int e = launch_cat_xgrad_reduce(xwp, cat_xgrad_records(dm), r.cout, p.d.in_channel, grads[xi], s)) return e;
+          if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
+          if (int e = launch_stats_finalize(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
+          mark("in_bwd:" + n);    // pass B
+          if (int e = launch_cat_bwd_x(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), xin, w2, p.d.in_channel, mu2, rs2,
+                                       r.cout, p.d.negative_slope, fat(p.m1), fat(p.m2), fat(p.m1b), fat(p.m2b), at(p.grad[o.dst]), nullptr,
+                                       nullptr, fat(p.xwp), dm, s)) return e;
+          if (grads[xi]) {
+            mark("stats");
+            if (int e = launch_cat_xgrad_reduce(fat(p.xwp), cat_xgrad_records(dm), r.cout, p.d.in_channel, grads[xi], s)) return e;
+          }
         } else {
+          const void* r2 = o.xname ? at(r.raw2) : nullptr;
+          if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
+                                     p.d.negative_slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dat(p.stats),
+                                     dat(p.stats2), dm, s)) return e;
+          mark("stats");
+          if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
+          if (o.xname)
+            if (int e = launch_stats_finalize(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
+          mark("in_bwd:" + n);    // pass B
           if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,
                                      p.d.negative_slope, fat(p.m1), fat(p.m2), o.xname ? fat(p.m1b) : nullptr,
                                      o.xname ? fat(p.m2b) : nullptr, at(p.grad[o.dst]), o.xname ? at(p.gx) : nullptr, nullptr, nullptr,

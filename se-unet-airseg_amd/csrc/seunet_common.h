@@ -234,10 +234,17 @@ int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* m
 
 // pooling / interpolation / heads (resample.hip)
 int cat_xgrad_records(Dims d);
-int launch_cat_bwd_xgrad(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
-                         const void* raw2, const float* mean2, const float* rstd2, int C, float slope, const float* m1,
-                         const float* m2, const float* m1b, const float* m2b, void* dx, const void* x_in,
-                         float* xw_partial, Dims d, hipStream_t s);
+int xbranch_moment_slots(Dims d);
+int launch_xbranch_moments(int dtype, const void* x_in, double* partial, Dims d, hipStream_t s);
+int launch_xbranch_stats(const double* partial, int slots, const float* w2, int C, int in_channel, int N, long long count,
+                         float eps, float* mean2, float* rstd2, hipStream_t s);
+int launch_cat_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
+                     int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, Dims d,
+                     hipStream_t s);
+int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,
+                     const float* w2, int in_channel, const float* mean2, const float* rstd2, int C, float slope,
+                     const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, double* stat_partial,
+                     double* stat_partial2, float* xw_partial, Dims d, hipStream_t s);
 int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_channel, float* dw, hipStream_t s);
 int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);
 int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void* g_in,

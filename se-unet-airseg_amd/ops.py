@@ -210,30 +210,46 @@ def cat_epilogue_bwd(g_out, raw, mean, rstd, raw2=None, mean2=None, rstd2=None, 
     return dx, dx2
 
 
-def cat_epilogue_bwd_xgrad(g_out, raw, mean, rstd, raw2, mean2, rstd2, x_in, in_channel, slope=0.01):
-    """Two-branch backward with the x-branch weight gradient fused into pass B (``seunet_cat_epilogue_bwd_xgrad``).
-    x_in: packed 8-channel input [N, D, H, W, 8].  Returns (dx, dW2 of shape (C, in_channel, 1, 1, 1))."""
+def cat_epilogue_x(g_out, raw, mean, rstd, x_in, w2, in_channel, slope=0.01, eps=1e-5):
+    """Two-branch aggregation block whose second branch (the 1x1x1 conv ``w2`` of the <= 2-channel network input) is
+    recomputed instead of stored (``seunet_xbranch_*``, ``seunet_cat_epilogue_fwd_x / bwd_x``).
+    x_in: packed 8-channel input [N, D, H, W, 8]; w2: (C, in_channel, 1, 1, 1) f32.
+    Returns (out, dx, dW2): forward output, gradient w.r.t. ``raw`` for the upstream ``g_out``, gradient of ``w2``."""
     lib = _lib.load()
     n, d, h, w, c = raw.shape
     dims = _dims_cl(raw)
+    code = _code(raw)
+    w2f = w2.contiguous().float().reshape(c, in_channel)
+    mslots = lib.seunet_xbranch_moment_slots(dims)
+    mom = torch.zeros((n, mslots, 5), dtype=torch.float64, device=raw.device)
+    _lib.check(lib.seunet_xbranch_moments(code, x_in.data_ptr(), mom.data_ptr(), dims, _s()), "xbranch_moments")
+    mean2 = torch.empty((n, c), dtype=torch.float32, device=raw.device)
+    rstd2 = torch.empty_like(mean2)
+    _lib.check(lib.seunet_xbranch_stats(mom.data_ptr(), mslots, w2f.data_ptr(), c, in_channel, n, d * h * w, eps, mean2.data_ptr(),
+                                        rstd2.data_ptr(), _s()), "xbranch_stats")
+    out = torch.empty_like(raw)
+    _lib.check(lib.seunet_cat_epilogue_fwd_x(code, raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x_in.data_ptr(), w2f.data_ptr(),
+                                             in_channel, mean2.data_ptr(), rstd2.data_ptr(), c, slope, out.data_ptr(), dims, _s()),
+               "cat_epilogue_fwd_x")
     slots = lib.seunet_epilogue_slots(dims)
     st = torch.zeros((n, slots, c, 2), dtype=torch.float64, device=raw.device)
     st2 = torch.zeros_like(st)
-    _lib.check(lib.seunet_cat_epilogue_bwd(_code(raw), g_out.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                           raw2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), c, slope, None, None, None, None,
-                                           None, None, st.data_ptr(), st2.data_ptr(), dims, _s()), "cat_epilogue_bwd (pass A)")
-    m1, m2 = stats_finalize(st, slots, d * h * w, 0.0, 1)
-    m1b, m2b = stats_finalize(st2, slots, d * h * w, 0.0, 1)
     records = lib.seunet_cat_xgrad_records(dims)
     part = torch.empty((records, c, 2), dtype=torch.float32, device=raw.device)
     dx = torch.empty_like(raw)
-    _lib.check(lib.seunet_cat_epilogue_bwd_xgrad(_code(raw), g_out.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                 raw2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), c, slope, m1.data_ptr(),
-                                                 m2.data_ptr(), m1b.data_ptr(), m2b.data_ptr(), dx.data_ptr(), x_in.data_ptr(),
-                                                 part.data_ptr(), dims, _s()), "cat_epilogue_bwd_xgrad")
+
+    def bwd(m1, m2, m1b, m2b, o, s1, s2, xp):
+        _lib.check(lib.seunet_cat_epilogue_bwd_x(code, g_out.data_ptr(), raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x_in.data_ptr(),
+                                                 w2f.data_ptr(), in_channel, mean2.data_ptr(), rstd2.data_ptr(), c, slope, _lib.ptr(m1),
+                                                 _lib.ptr(m2), _lib.ptr(m1b), _lib.ptr(m2b), _lib.ptr(o), _lib.ptr(s1), _lib.ptr(s2),
+                                                 _lib.ptr(xp), dims, _s()), "cat_epilogue_bwd_x")
+    bwd(None, None, None, None, None, st, st2, None)
+    m1, m2 = stats_finalize(st, slots, d * h * w, 0.0, 1)
+    m1b, m2b = stats_finalize(st2, slots, d * h * w, 0.0, 1)
+    bwd(m1, m2, m1b, m2b, dx, None, None, part)
     dw = torch.zeros((c, in_channel, 1, 1, 1), dtype=torch.float32, device=raw.device)
     _lib.check(lib.seunet_cat_xgrad_reduce(part.data_ptr(), records, c, in_channel, dw.data_ptr(), _s()), "cat_xgrad_reduce")
-    return dx, dw
+    return out, dx, dw
 
 
 # ---- pooling / interpolation / heads ---------------------------------------------------------------------
