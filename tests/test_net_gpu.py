@@ -345,3 +345,23 @@ def test_full_size_properties_128(A, orc, dtype):
     gs = [p.grad for n, p in m.named_parameters() if not n.startswith("dc62.")]
     assert all(g is not None and torch.isfinite(g).all() for g in gs)
     assert m.dc62.conv1.weight.grad is None
+
+
+def test_three_channel_input_takes_the_materialised_x_branch_fp32(A, orc):
+    """in_channel = 3: the x-branches (x33 / x63 / x93) are not recomputed from the input (that path handles <= 2
+    channels) but run as 1x1x1 convolutions with their own MFMA weight-gradient launch.  Forward and gradients against
+    the oracle on the same weights."""
+    torch.manual_seed(0)
+    o = orc.build_oracle(3, 1, 1, seed=0)
+    m = A.SE_UNet(3, 1, act_dtype="fp32", conv_impl=0)
+    m.load_state_dict(orc.deterministic_state_dict(3, 1, 1, 0))
+    m = m.cuda().eval()
+    b = orc.synthetic_batch(1, (32, 32, 32), 3, seed=9)
+    pe, pd = o(b["image"])
+    orc.stage_loss(1, pe, pd, b["label"]).backward()
+    e, d = m(b["image"].cuda())
+    assert float((d.detach().cpu() - pd.detach()).abs().max()) < 1e-4 and float((e.detach().cpu() - pe.detach()).abs().max()) < 1e-4
+    A.fused_stage_loss(1, e, d, b["label"].cuda()).backward()
+    for name in ("x33.conv1.weight", "x63.conv1.weight", "x93.conv1.weight", "ec33.conv1.weight"):
+        gq, gp = dict(o.named_parameters())[name].grad, dict(m.named_parameters())[name].grad.cpu()
+        assert float((gp - gq).norm() / gq.norm()) < 2e-2, name          # fp32-vs-fp32 flip noise band (see _check_grad_noise)
