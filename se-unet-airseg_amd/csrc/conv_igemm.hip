@@ -3,29 +3,31 @@
 // weights).  Reference ops: nn.Conv3d at SE_UNet.py:15,42,57 (+ torch.cat at :186,195,204,212,216,218,
 // 222,224,228 which is fused here as a multi-pointer channel concatenation).
 //
-//   GEMM view     M = voxels, N = output channels, K = taps x input channels
+//   GEMM view     output channels x voxels, K = taps x input channels.  The WEIGHTS are the MFMA's A operand, so the
+//                 accumulators hold the transposed tile: a lane owns one voxel (x = lane % 32) and runs of 4
+//                 consecutive output channels -- what a channels-last store wants
 //   workgroup     256 threads = 4 waves; output tile 4(z) x 4(y) x 32(x) voxels; wave w owns z-slice w,
-//                 i.e. four 32-voxel x-rows, times all N columns of the tile (32 or 64)
+//                 i.e. four 32-voxel x-rows, times all output-channel columns of the tile (32 or 64)
 //   dilation 2    decomposes into 8 independent dilation-1 problems on the parity sub-lattices
 //                 (voxel = 2*lattice + parity): the tile lives on one sub-lattice, so the halo is 1 lattice
 //                 voxel (39 KB tile) instead of 2 voxels (74 KB), and the rest of the kernel is unchanged
 //   MFMA          bf16: v_mfma_f32_32x32x16_bf16 (K-step = 16 channels of one tap)
 //                 f32 : v_mfma_f32_32x32x2_f32   (exact f32 FMA chain; the 1e-3 parity mode)
-//   LDS           input halo tile [6*6*34 voxels][32 B = one K-chunk], 16-B slots XOR-swizzled by voxel bit 3
-//                 so a ds_read_b128 of 16 consecutive voxels is conflict-free; weight slab
-//                 [tap][k-half][column][8 x bf16] (one contiguous 16-B fragment per lane)
-//   K loop        chunks of 32 bytes of channels (16 bf16 / 8 f32).  The NEXT chunk's tile and weights are
-//                 fetched into registers while the current chunk's 27 taps of MFMAs run, and written to LDS
-//                 after the barrier (split issue-early / write-late staging).  The fetches are
-//                 buffer_load_dwordx4 through wave-uniform descriptors: 32-bit offsets, and the hardware
-//                 range check returns zeros for padding voxels / channels, so there is no branch and no
-//                 64-bit address arithmetic in the loop (each wave fetches one 16-B piece index of 64
-//                 consecutive halo voxels per instruction)
-//   epilogue      + bias; per-(n,c) InstanceNorm partial sums (shifted f32 sums per register row, f64 across rows,
-//                 fixed-order cross-wave sum); each wave transposes its own 128 voxels through a private LDS
-//                 stage (no workgroup barrier) so that every lane stores 16 B (8 channels of one voxel),
-//                 optionally += (gradient accumulation) and split over up to three destination tensors
-//                 (backward of the fused concatenation)
+//   LDS           input halo tile, planar: [16-B piece of the 32-B channel chunk][6*6*34 voxels][16 B]; weight slab
+//                 [tap][k-half][column][16 B].  Every fragment address is "lane base + immediate": no swizzle, no
+//                 address arithmetic in the K loop, conflict-free reads and writes
+//   K loop        chunks of 32 bytes of channels (16 bf16 / 8 f32).  The NEXT chunk's tile and weights are fetched
+//                 into registers while the current chunk's 27 taps of MFMAs run, and written to LDS after the barrier.
+//                 The fetches are buffer_load_dwordx4 through wave-uniform descriptors: 32-bit offsets, hardware range
+//                 check returns zeros for padding voxels / channels; lane pairs fetch the two pieces of one voxel
+//                 (32 contiguous bytes) unless a concatenation boundary splits a chunk.  The MFMA loop is pipelined
+//                 by hand: the fragments of tap t+1 are requested before the MFMAs of tap t issue
+//   epilogue      + bias; per-(n,c) InstanceNorm partial sums by a DPP reduce-scatter over the 32 voxel lanes (f32 tree
+//                 for bf16 activations, exact f64 in the f32 parity mode) and a fixed-order cross-wave sum behind one
+//                 LDS-only barrier; stores straight from the accumulators when every destination has <= 16 channels,
+//                 otherwise through a wave-private ds_write_b64 restage so that each lane stores 16 contiguous bytes;
+//                 optionally += (gradient accumulation) and split over up to three destination tensors (backward of
+//                 the fused concatenation)
 //   grid          blockIdx.x is remapped so that each XCD (private L2) owns a contiguous run of tiles
 #include "seunet_common.h"
 #include <utility>

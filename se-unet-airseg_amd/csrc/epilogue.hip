@@ -8,9 +8,12 @@
 //
 // Thread mapping: one lane owns 8 consecutive channels (16 B bf16 / 32 B f32) of one voxel,
 // LPV = C/8 consecutive lanes own one voxel, so every global access is a fully coalesced
-// 16/32-byte-per-lane stream; the per-voxel channel dot products of the gates are LPV-lane
-// xor-shuffle reductions (wave64), the per-(n,c) InstanceNorm sums are strided shuffle
-// reductions + a fixed-order cross-wave sum (deterministic, no atomics).
+// 16/32-byte-per-lane stream, software-pipelined one voxel ahead; the per-voxel channel dot products of the gates are
+// LPV-lane reductions on DPP (quad_perm / row_half_mirror / row_mirror), the per-(n,c) InstanceNorm sums are f64:
+// strided shuffle reductions + a fixed-order cross-wave sum (deterministic, no atomics).
+// The "x" branch of an aggregation block (a 1x1x1 conv of the <= 2-channel network input) is recomputed per voxel
+// instead of read, its statistics come from the input's second moments, and its weight gradient is accumulated in the
+// backward pass B (XR / XW template modes below).
 #include "seunet_common.h"
 
 namespace seunet {

@@ -3,16 +3,21 @@
 // (backward of nn.Conv3d at reference SE_UNet.py:15,42,57; X may be a fused channel concatenation.)
 //
 //   GEMM view   M = input channels (32 per workgroup), N = output channels (32), K = voxels
-//   workgroup   256 threads = 4 waves, persistent over spatial tiles; LDS holds the X halo tile and the
-//               dY tile as [voxel][32 channels]; the 27 taps are split over the 4 waves (7/7/7/6), each wave
-//               keeping one 32x32 f32 accumulator per tap in registers across ALL its tiles
+//   workgroup   256 threads = 4 waves, persistent over spatial tiles, two workgroups per CU (one computes while the other's
+//               tile is in flight); the 27 taps are split over the 4 waves (7/7/7/6), each wave keeping one 32x32 f32
+//               accumulator per tap in registers across ALL its tiles
+//   staging     LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write phase.  LDS image planar,
+//               [16-B piece of the 32 channels][voxel][16 B]; padding voxels / channels read a zero page.  The DMA plan is
+//               per workgroup: packed halo coordinates parked in LDS, scalar tensor bases, ~16 vector instructions per DMA
 //   MFMA        bf16: v_mfma_f32_32x32x16_bf16, K-step = 16 consecutive x-voxels.  Both operands need "8 voxels of
 //               one channel" per lane while the data is [voxel][channel]: gfx950's transposing LDS read
 //               ds_read_b64_tr_b16 delivers exactly that from the unmodified image (a 16-lane group reads a
-//               4-voxel x 16-channel block, 64-B rows -> conflict-free), tap shifts only move the row address.
+//               4-voxel x 16-channel block -> conflict-free), tap shifts only move the row address (tap base register +
+//               immediate).  The phase is pipelined by hand: fragments are requested two MFMAs ahead.
 //               f32 : v_mfma_f32_32x32x2_f32 (K-step = 2 voxels, one element per lane, plain loads)
-//   output      each workgroup stores its accumulators once to a slab; a second kernel sums the slabs in a
-//               fixed order (deterministic, no atomics) straight into the PyTorch (Cout,Cin,3,3,3) layout
+//   output      each workgroup stores its accumulators once to a slab (1x1x1: after summing its four waves in LDS); a
+//               second kernel sums the slabs 16-way parallel in a fixed order (deterministic, no atomics, f64) straight
+//               into the PyTorch (Cout,Cin,3,3,3) layout
 #include "seunet_common.h"
 #include <utility>
 
