@@ -365,3 +365,22 @@ def test_three_channel_input_takes_the_materialised_x_branch_fp32(A, orc):
     for name in ("x33.conv1.weight", "x63.conv1.weight", "x93.conv1.weight", "ec33.conv1.weight"):
         gq, gp = dict(o.named_parameters())[name].grad, dict(m.named_parameters())[name].grad.cpu()
         assert float((gp - gq).norm() / gq.norm()) < 2e-2, name          # fp32-vs-fp32 flip noise band (see _check_grad_noise)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_gradients_are_bitwise_reproducible(A, orc, dtype):
+    """Every reduction on the path (InstanceNorm partial sums, parameter-gradient records, weight-gradient slabs, loss
+    sums) is summed in a fixed order and nothing uses atomics: two runs of the same step give identical bits."""
+    b = orc.synthetic_batch(2, (64, 64, 64), 2, seed=11)
+    x, lab = b["image"].cuda(), b["label"].cuda()
+    runs = []
+    for _ in range(2):
+        m = build(A, orc, 2, dtype)
+        e, d = m(x)
+        loss = A.fused_stage_loss(1, e, d, lab)
+        loss.backward()
+        runs.append((loss.detach().clone(), d.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2].keys() == runs[1][2].keys() and len(runs[0][2]) == 116
+    for n in runs[0][2]:
+        assert torch.equal(runs[0][2][n], runs[1][2][n]), n
