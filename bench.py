@@ -180,7 +180,9 @@ def main():
             avg = ms / cnt
             kernels.append({"kernel": tag, "avg_ms": avg, "launches": cnt, "share_of_step": ms / (1e3 * dt),
                             "tflops": fl / (avg * 1e-3) / 1e12 if fl else None, "gbs": by / (avg * 1e-3) / 1e9 if by else None})
-        dom = next((k for k in kernels if k["kernel"] != "outside"), None)
+        # dominant kernel: the per-layer launch group (one launch per step) with the largest total time; the aggregated
+        # classes of many small launches ("stats", "up_bwd", ...) are listed in "kernels" but are not one kernel
+        dom = next((k for k in kernels if ":" in k["kernel"]), None) or next((k for k in kernels if k["kernel"] != "outside"), None)
         if dom is not None:
             if dom["tflops"]:
                 out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_TFLOPS[args.dtype],
