@@ -65,10 +65,8 @@ channel_stats_kernel(const T* __restrict__ t, int C, double* __restrict__ partia
 // one 256-thread block per (n, c): sums the f64 partial slots in a fixed order.
 //   mode 0: (mean, rstd = 1/sqrt(biased var + eps))      [InstanceNorm3d forward]
 //   mode 1: (sum/count, sumsq/count)                     [the two means of the InstanceNorm backward]
-__global__ void __launch_bounds__(256)
-stats_finalize_kernel(const double* __restrict__ partial, int slots, int C, int N, double inv_count,
-                      float eps, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
-  const int idx = blockIdx.x;  // (n, c)
+__device__ __forceinline__ void stats_finalize_body(int idx, const double* __restrict__ partial, int slots, int C, double inv_count,
+                                                    float eps, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
   const int n = idx / C, c = idx % C;
   double s1 = 0.0, s2 = 0.0;
   for (int p = threadIdx.x; p < slots; p += 256) {
@@ -98,6 +96,11 @@ stats_finalize_kernel(const double* __restrict__ partial, int slots, int C, int 
       out_b[idx] = (float)(s2 * inv_count);
     }
   }
+}
+__global__ void __launch_bounds__(256)
+stats_finalize_kernel(const double* __restrict__ partial, int slots, int C, int N, double inv_count,
+                      float eps, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
+  stats_finalize_body(blockIdx.x, partial, slots, C, inv_count, eps, mode, out_a, out_b);
 }
 
 // ----------------------------------------------------------------------------------
@@ -373,11 +376,10 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
 }
 
 // sums the per-block parameter-gradient records; one wave per entry, f64, fixed order
-__global__ void __launch_bounds__(256)
-pgrad_reduce_kernel(const float* __restrict__ pg, int records, int C, float* dw_se, float* dw_se2,
-                    float* dw_side, float* db_side, float* dhead_w) {
+__device__ __forceinline__ void pgrad_reduce_body(int blk, const float* __restrict__ pg, int records, int C, float* dw_se,
+                                                  float* dw_se2, float* dw_side, float* db_side, float* dhead_w) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + wave, K = 4 * C + 4;
+  const int k = blk * 4 + wave, K = 4 * C + 4;
   if (k >= K) return;
   double s = 0.0;
   for (int r = lane; r < records; r += 64) s += (double)pg[(long long)r * K + k];
@@ -390,6 +392,20 @@ pgrad_reduce_kernel(const float* __restrict__ pg, int records, int C, float* dw_
   else if (k < 4 * C) { if (dw_side) dw_side[k - 2 * C] = v; }
   else if (k < 4 * C + 2) { if (db_side) db_side[k - 4 * C] = v; }
   else { if (dhead_w) dhead_w[k - 4 * C - 2] = v; }
+}
+__global__ void __launch_bounds__(256)
+pgrad_reduce_kernel(const float* __restrict__ pg, int records, int C, float* dw_se, float* dw_se2,
+                    float* dw_side, float* db_side, float* dhead_w) {
+  pgrad_reduce_body(blockIdx.x, pg, records, C, dw_se, dw_se2, dw_side, db_side, dhead_w);
+}
+// what follows pass A of a gated block, in ONE launch: the two means of the InstanceNorm backward (blocks [0, N*C)) and the
+// parameter-gradient records (the remaining blocks) -- two dependent 5-us launches on the critical path otherwise
+__global__ void __launch_bounds__(256)
+gate_bwd_finalize_kernel(const double* __restrict__ partial, int slots, int C, int N, double inv_count, float* __restrict__ m1,
+                         float* __restrict__ m2, const float* __restrict__ pg, int records, float* dw_se, float* dw_se2,
+                         float* dw_side, float* db_side, float* dhead_w) {
+  if ((int)blockIdx.x < N * C) stats_finalize_body(blockIdx.x, partial, slots, C, inv_count, 0.f, 1, m1, m2);
+  else pgrad_reduce_body((int)blockIdx.x - N * C, pg, records, C, dw_se, dw_se2, dw_side, db_side, dhead_w);
 }
 
 // ----------------------------------------------------------------------------------
@@ -741,6 +757,15 @@ int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* r
   SEUNET_CHECK(m2 && draw_out, "gate_epilogue_bwd pass B needs m2 and the output tensor");
   return dtype == SEUNET_BF16 ? sse_bwd_t<bf16_t, true>(raw, mean, rstd, C, p, g, head, m1, m2, draw_out, nullptr, nullptr, d, s)
                               : sse_bwd_t<float, true>(raw, mean, rstd, C, p, g, head, m1, m2, draw_out, nullptr, nullptr, d, s);
+}
+
+int launch_gate_bwd_finalize(const double* stat_partial, int slots, int C, int N, long long count, float* m1, float* m2,
+                             const float* pgrad_partial, int records, float* dw_se, float* dw_se2, float* dw_side,
+                             float* db_side, float* dhead_w, hipStream_t s) {
+  gate_bwd_finalize_kernel<<<N * C + cdiv(4 * C + 4, 4), 256, 0, s>>>(stat_partial, slots, C, N, 1.0 / (double)count, m1, m2,
+                                                                     pgrad_partial, records, dw_se, dw_se2, dw_side, db_side, dhead_w);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* dw_se, float* dw_se2,

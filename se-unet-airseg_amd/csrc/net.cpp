@@ -473,12 +473,12 @@ struct Exec {
         if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd, nullptr, nullptr,
                                    nullptr, dat(p.stats), fat(p.pgrad), dm, s)) return e;
         mark("stats");
-        if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
         float* g_head = grads[find_param(reg, o.head == 0 ? "dc0_0.weight" : "dc0_1.weight")];
         const int i_se2 = o.gates == 2 ? find_param(reg, n + ".conv_se2.weight") : -1;
-        if (int e = launch_pgrad_reduce(fat(p.pgrad), dm.N * P_slots, r.cout, grads[find_param(reg, n + ".conv_se.weight")],
-                                        i_se2 >= 0 ? grads[i_se2] : nullptr, grads[find_param(reg, n + ".conv2.weight")],
-                                        grads[find_param(reg, n + ".conv2.bias")], g_head ? g_head + 2 * o.m : nullptr, s)) return e;
+        if (int e = launch_gate_bwd_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1), fat(p.m2), fat(p.pgrad),
+                                             dm.N * P_slots, grads[find_param(reg, n + ".conv_se.weight")],
+                                             i_se2 >= 0 ? grads[i_se2] : nullptr, grads[find_param(reg, n + ".conv2.weight")],
+                                             grads[find_param(reg, n + ".conv2.bias")], g_head ? g_head + 2 * o.m : nullptr, s)) return e;
         mark("in_bwd:" + n);    // pass B: recompute dxhat, apply the InstanceNorm backward, store draw over g_e
         if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd, fat(p.m1), fat(p.m2),
                                    at(p.grad[o.dst]), nullptr, nullptr, dm, s)) return e;

@@ -220,6 +220,9 @@ int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* r
                    const SseParams& p, const SseBwdIn& g, const SseHead& head, const float* m1,
                    const float* m2, void* draw_out, double* stat_partial, float* pgrad_partial,
                    Dims d, hipStream_t s);
+int launch_gate_bwd_finalize(const double* stat_partial, int slots, int C, int N, long long count, float* m1, float* m2,
+                             const float* pgrad_partial, int records, float* dw_se, float* dw_se2, float* dw_side,
+                             float* db_side, float* dhead_w, hipStream_t s);
 int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* dw_se,
                         float* dw_se2, float* dw_side, float* db_side, float* dhead_w,
                         hipStream_t s);
