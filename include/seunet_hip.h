@@ -198,6 +198,7 @@ int seunet_net_backward(const seunet_net_desc* desc, const float* const* params,
  * stream; process-wide, meant for one benchmarking thread at a time).  seunet_prof_report writes "tag<TAB>ms<TAB>count" lines and resets; it waits on
  * the recorded events, so call it outside any timed region. */
 int seunet_prof_enable(int on);
+int seunet_prof_enable_filtered(const char* tag_substring);   /* time only the launch groups whose tag contains it */
 int seunet_prof_report(char* buf, size_t cap);
 
 #ifdef __cplusplus

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "seunet_net_workspace_bytes": (_sz, [C.POINTER(NetDesc)]),
     "seunet_net_forward": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "seunet_prof_enable": (_i, [_i]),
+    "seunet_prof_enable_filtered": (_i, [C.c_char_p]),
     "seunet_prof_report": (_i, [C.c_char_p, _sz]),
     "seunet_net_backward": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _pp, _vp, _sz, _vp]),
 }
