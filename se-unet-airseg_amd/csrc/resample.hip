@@ -348,39 +348,55 @@ struct HeadLevels {
   const float* map[4];  // level l has extents (D0>>l, H0>>l, W0>>l); null = level absent
 };
 
-__global__ void head_fwd_kernel(HeadLevels lv, const float* __restrict__ bias, float* __restrict__ pred,
-                                int D, int H, int W, long long total) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+// One thread = 4 consecutive x of one (n, z, y) row: the z / y source rows and weights of every level are shared by the
+// four outputs (the per-voxel form spent ~260 vector instructions per voxel, 87 us per head at 4x128^3).
+__global__ void __launch_bounds__(256)
+head_fwd_kernel(HeadLevels lv, const float* __restrict__ bias, float* __restrict__ pred,
+                int D, int H, int W, long long total4) {
+  const int W4 = W >> 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
        i += (long long)gridDim.x * blockDim.x) {
     long long r = i;
-    const int xo = (int)(r % W); r /= W;
+    const int xq = (int)(r % W4); r /= W4;
     const int yo = (int)(r % H); r /= H;
     const int zo = (int)(r % D);
     const long long n = r / D;
-    float acc = bias[0];
-    if (lv.map[0]) acc += lv.map[0][i];
+    const long long o = ((n * D + zo) * H + yo) * (long long)W + 4 * xq;
+    float acc[4];
+    const float b0 = bias[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = b0;
+    if (lv.map[0]) {
+      const float4 v = *reinterpret_cast<const float4*>(lv.map[0] + o);
+      acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+    }
 #pragma unroll
     for (int l = 1; l < 4; ++l) {
       if (!lv.map[l]) continue;
       const int Dl = D >> l, Hl = H >> l, Wl = W >> l;
-      int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+      int z0, z1, y0, y1; float lz, ly;
       ac_src(zo, ac_scale(Dl, D), Dl, z0, z1, lz);
       ac_src(yo, ac_scale(Hl, H), Hl, y0, y1, ly);
-      ac_src(xo, ac_scale(Wl, W), Wl, x0, x1, lx);
       const float* m = lv.map[l] + n * (long long)Dl * Hl * Wl;
-      float a = 0.f;
+      const float* r00 = m + ((long long)z0 * Hl + y0) * Wl;
+      const float* r01 = m + ((long long)z0 * Hl + y1) * Wl;
+      const float* r10 = m + ((long long)z1 * Hl + y0) * Wl;
+      const float* r11 = m + ((long long)z1 * Hl + y1) * Wl;
+      const float w00 = (1.f - lz) * (1.f - ly), w01 = (1.f - lz) * ly, w10 = lz * (1.f - ly), w11 = lz * ly;
+      const float rx = ac_scale(Wl, W);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int z = (k & 4) ? z1 : z0, y = (k & 2) ? y1 : y0, x = (k & 1) ? x1 : x0;
-        const float w = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
-        a += w * m[((long long)z * Hl + y) * Wl + x];
+      for (int k = 0; k < 4; ++k) {
+        int x0, x1; float lx;
+        ac_src(4 * xq + k, rx, Wl, x0, x1, lx);
+        // same association as the 8-corner sum: (wz*wy)*wx per corner
+        const float a0 = w00 * r00[x0] + w01 * r01[x0] + w10 * r10[x0] + w11 * r11[x0];
+        const float a1 = w00 * r00[x1] + w01 * r01[x1] + w10 * r10[x1] + w11 * r11[x1];
+        acc[k] += (1.f - lx) * a0 + lx * a1;
       }
-      acc += a;
     }
-    pred[i] = acc;
+    *reinterpret_cast<float4*>(pred + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
-
 // transposed 1-D interpolation along one axis of an f32 tensor viewed as [outer][O][inner] -> [outer][I][inner]
 __global__ void up_transpose_axis_kernel(const float* __restrict__ in, float* __restrict__ out, int I, int O,
                                          long long inner, long long total) {
@@ -554,8 +570,9 @@ int launch_head_fwd(const float* const* level_maps, int nlevels, const float* bi
   for (int l = 0; l < 4; ++l) lv.map[l] = l < nlevels ? level_maps[l] : nullptr;
   for (int l = 1; l < nlevels; ++l)
     SEUNET_CHECK((d0.D >> l) >= 1 && (d0.H >> l) >= 1 && (d0.W >> l) >= 1, "head: volume too small for level %d", l);
-  const long long total = (long long)d0.N * d0.vox();
-  head_fwd_kernel<<<grid_for(total), 256, 0, s>>>(lv, bias, pred, d0.D, d0.H, d0.W, total);
+  SEUNET_CHECK(d0.W % 4 == 0, "head: W=%d must be a multiple of 4", d0.W);
+  const long long total4 = (long long)d0.N * d0.vox() / 4;
+  head_fwd_kernel<<<grid_for(total4), 256, 0, s>>>(lv, bias, pred, d0.D, d0.H, d0.W, total4);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
