@@ -127,6 +127,19 @@ def registry(desc: _lib.NetDesc) -> List[Tuple[str, Tuple[int, ...]]]:
     return out
 
 
+def alloc_flat_grads(params, dead, device):
+    """One contiguous f32 buffer for the gradients of all LIVE parameters, in registry order, plus per-parameter
+    views of it (``None`` for the dead ``dc62`` block, which takes no space: the live gradients are back to back, so
+    ``ddp.allreduce_gradients`` reduces the buffer in place with ONE collective)."""
+    sizes = [0 if d else p.numel() for p, d in zip(params, dead)]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    grads, off = [], 0
+    for p, n, d in zip(params, sizes, dead):
+        grads.append(None if d else flat[off:off + n].view(p.shape))
+        off += n
+    return flat, grads
+
+
 class _SEUNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, drop1, drop2, meta, *params):
@@ -134,17 +147,21 @@ class _SEUNetFunction(torch.autograd.Function):
         b, _, d, h, w = x.shape
         desc = make_desc(b, meta["in_channel"], meta["n_classes"], d, h, w, meta["width_mult"],
                          meta["dtype"], meta["conv_impl"], meta["negative_slope"])
-        ws_bytes = lib.seunet_net_workspace_bytes(C.byref(desc))
-        if ws_bytes == 0:
-            raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-        pred0 = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
-        pred1 = torch.empty_like(pred0)
-        plist = [p.detach().contiguous() for p in params]
-        parr = _lib.ptr_array(plist)
-        _lib.check(lib.seunet_net_forward(C.byref(desc), parr, x.data_ptr(), _lib.ptr(drop1), _lib.ptr(drop2),
-                                          pred0.data_ptr(), pred1.data_ptr(), ws.data_ptr(), ws_bytes,
-                                          _lib.stream_ptr()), "net_forward")
+        with torch.cuda.device(x.device):       # launch on x's GPU and stream even when it is not the current device
+            ws_bytes = lib.seunet_net_workspace_bytes(C.byref(desc))
+            if ws_bytes == 0:
+                raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            pred0 = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
+            pred1 = torch.empty_like(pred0)
+            plist = [p.detach().contiguous() for p in params]
+            for p in plist:
+                if p.device != x.device:
+                    raise RuntimeError(f"SE_UNet parameters are on {p.device} but the input is on {x.device}")
+            parr = _lib.ptr_array(plist)
+            _lib.check(lib.seunet_net_forward(C.byref(desc), parr, x.data_ptr(), _lib.ptr(drop1), _lib.ptr(drop2),
+                                              pred0.data_ptr(), pred1.data_ptr(), ws.data_ptr(), ws_bytes,
+                                              _lib.stream_ptr()), "net_forward")
         ctx.desc, ctx.ws, ctx.ws_bytes = desc, ws, ws_bytes
         ctx.plist, ctx.drop = plist, (drop1, drop2)
         ctx.dead = meta["dead"]
@@ -152,23 +169,23 @@ class _SEUNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g0, g1):
+        if ctx.ws is None:
+            raise RuntimeError("SE_UNet (HIP path): the backward pass of this forward call has already run; it consumes "
+                               "the saved workspace, so a second backward (retain_graph=True, or two losses "
+                               "back-propagated separately) is not supported -- sum the losses and call backward once")
         lib = _lib.load()
         dev = ctx.ws.device
         shape = (ctx.desc.batch, 1, ctx.desc.d, ctx.desc.h, ctx.desc.w)
-        g0 = torch.zeros(shape, dtype=torch.float32, device=dev) if g0 is None else g0.contiguous().float()
-        g1 = torch.zeros(shape, dtype=torch.float32, device=dev) if g1 is None else g1.contiguous().float()
-        # all parameter gradients live in ONE flat buffer (one RCCL all-reduce under data parallelism)
-        sizes = [p.numel() for p in ctx.plist]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        grads, off = [], 0
-        for p, n, dead in zip(ctx.plist, sizes, ctx.dead):
-            grads.append(None if dead else flat[off:off + n].view_as(p))
-            off += n
-        garr = _lib.ptr_array(grads)
-        parr = _lib.ptr_array(ctx.plist)
-        _lib.check(lib.seunet_net_backward(C.byref(ctx.desc), parr, g0.data_ptr(), g1.data_ptr(),
-                                           _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
-                                           ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr()), "net_backward")
+        with torch.cuda.device(dev):
+            g0 = torch.zeros(shape, dtype=torch.float32, device=dev) if g0 is None else g0.contiguous().float()
+            g1 = torch.zeros(shape, dtype=torch.float32, device=dev) if g1 is None else g1.contiguous().float()
+            # all live parameter gradients are views of ONE flat buffer (one RCCL all-reduce under data parallelism)
+            _, grads = alloc_flat_grads(ctx.plist, ctx.dead, dev)
+            garr = _lib.ptr_array(grads)
+            parr = _lib.ptr_array(ctx.plist)
+            _lib.check(lib.seunet_net_backward(C.byref(ctx.desc), parr, g0.data_ptr(), g1.data_ptr(),
+                                               _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
+                                               ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr()), "net_backward")
         ctx.ws = None
         return (None, None, None, None) + tuple(grads)
 
@@ -239,6 +256,9 @@ class SE_UNet(nn.Module):
                                "(the CPU oracle lives in oracle/seunet_oracle.py and is test infrastructure).")
         if x.dim() != 5 or x.shape[1] != self.in_channel:
             raise ValueError(f"expected input (B,{self.in_channel},D,H,W), got {tuple(x.shape)}")
+        if x.requires_grad:
+            raise NotImplementedError("SE_UNet (HIP path) computes no gradient with respect to its input (no reference "
+                                      "caller asks for one); detach() the input")
         x = x.contiguous().float()          # callers pass strided views
         b = x.shape[0]
         if drop_scales is not None:

@@ -341,10 +341,10 @@ struct Exec {
       const OpRes& r = p.op[i];
       const std::string n = o.name;
       if (o.kind == OP_POOL) {
-        mark("pool_fwd");
+        mark("pool_fwd:" + n);
         if (int e = launch_maxpool_fwd(p.d.dtype, at(p.feat[o.src[0]]), p.C[o.src[0]], at(p.feat[o.dst]), p.dims[kT[o.src[0]].level], s)) return e;
       } else if (o.kind == OP_UP) {
-        mark("up_fwd");
+        mark("up_fwd:" + n);
         if (int e = launch_upsample2_fwd(p.d.dtype, at(p.feat[o.src[0]]), p.C[o.src[0]], at(p.feat[o.dst]), p.dims[kT[o.src[0]].level], s)) return e;
       } else if (o.kind == OP_GATED) {
         const int lv = kT[o.dst].level;
@@ -449,7 +449,7 @@ struct Exec {
         const int t = o.src[0];
         if (is_input(t)) continue;
         SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
-        mark(o.kind == OP_POOL ? "pool_bwd" : "up_bwd");
+        mark((o.kind == OP_POOL ? "pool_bwd:" : "up_bwd:") + n);
         if (o.kind == OP_POOL) {
           if (int e = launch_maxpool_bwd(p.d.dtype, at(p.feat[t]), at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
                                          p.dims[kT[t].level], s)) return e;

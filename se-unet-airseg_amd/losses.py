@@ -29,10 +29,11 @@ def _prep(t: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tenso
 def _sums(pred, apply_sigmoid, target, weight, skel, group):
     lib = _lib.load()
     n = pred.numel()
-    partial = torch.empty(lib.seunet_loss_partial_floats(), dtype=torch.float32, device=pred.device)
-    sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=pred.device)
-    _lib.check(lib.seunet_loss_sums(pred.data_ptr(), int(apply_sigmoid), target.data_ptr(), _lib.ptr(weight), _lib.ptr(skel),
-                                    n, partial.data_ptr(), sums.data_ptr(), _lib.stream_ptr()), "loss_sums")
+    with torch.cuda.device(pred.device):    # launch on pred's GPU even when it is not the current device
+        partial = torch.empty(lib.seunet_loss_partial_floats(), dtype=torch.float32, device=pred.device)
+        sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=pred.device)
+        _lib.check(lib.seunet_loss_sums(pred.data_ptr(), int(apply_sigmoid), target.data_ptr(), _lib.ptr(weight), _lib.ptr(skel),
+                                        n, partial.data_ptr(), sums.data_ptr(), _lib.stream_ptr()), "loss_sums")
     if group is not None:
         import torch.distributed as dist
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group if group is not True else None)
@@ -67,11 +68,12 @@ class _RatioLoss(torch.autograd.Function):
     def backward(ctx, g):
         p, t, w, s, sums = ctx.saved
         c_dice, c_gul, c_atr, sig = ctx.coef
-        gp = torch.empty_like(p)
-        gs = g.detach().reshape(1).to(torch.float32).contiguous()
-        _lib.check(_lib.load().seunet_loss_grad(p.data_ptr(), int(sig), t.data_ptr(), _lib.ptr(w), _lib.ptr(s), p.numel(),
-                                                sums.data_ptr(), c_dice, c_gul, c_atr, 1.0, gs.data_ptr(), gp.data_ptr(),
-                                                _lib.stream_ptr()), "loss_grad")
+        with torch.cuda.device(p.device):
+            gp = torch.empty_like(p)
+            gs = g.detach().reshape(1).to(p.device, torch.float32).contiguous()
+            _lib.check(_lib.load().seunet_loss_grad(p.data_ptr(), int(sig), t.data_ptr(), _lib.ptr(w), _lib.ptr(s), p.numel(),
+                                                    sums.data_ptr(), c_dice, c_gul, c_atr, 1.0, gs.data_ptr(), gp.data_ptr(),
+                                                    _lib.stream_ptr()), "loss_grad")
         return gp.reshape(ctx.shape), None, None, None, None, None, None, None, None
 
 

@@ -90,15 +90,18 @@ def _ddp_worker(rank, world, port, q):
     torch.manual_seed(0)
     m = A.SE_UNet(2, 1)
     ddp.broadcast_parameters(m)
-    # gradients laid out the way SE_UNet's backward produces them: views of one flat buffer, dc62 skipped
+    # gradients laid out by the very helper SE_UNet's backward uses: views of one flat buffer, the dead dc62 block
+    # (mid-list in registry order) takes no space, so the live gradients are back to back
+    from seunet_amd.SE_UNet import alloc_flat_grads
+    plist = list(m.parameters())
+    flat, grads = alloc_flat_grads(plist, m._dead, torch.device("cpu"))
+    flat.copy_(torch.arange(flat.numel(), dtype=torch.float32) * (rank + 1))
+    for p, g in zip(plist, grads):
+        p.grad = g
     live = [p for n, p in m.named_parameters() if not n.startswith("dc62.")]
-    flat = torch.arange(sum(p.numel() for p in live), dtype=torch.float32) * (rank + 1)
-    off = 0
-    for p in live:
-        p.grad = flat[off:off + p.numel()].view_as(p)
-        off += p.numel()
+    zero_copy = ddp._flat_view([p.grad for p in m.parameters() if p.grad is not None]) is not None
     n = ddp.allreduce_gradients(m.parameters())
-    ok_flat = n == 1_520_314 - m.dc62.conv1.weight.numel() and torch.equal(flat, torch.arange(n, dtype=torch.float32) * 3)
+    ok_flat = zero_copy and n == 1_520_314 - m.dc62.conv1.weight.numel() and torch.equal(flat, torch.arange(n, dtype=torch.float32) * 3)
     # fallback path: separately allocated gradients
     for p in live:
         p.grad = torch.full_like(p, float(rank + 1))

@@ -103,13 +103,15 @@ def _rel_errors(model, ref64):
 
 def _check_grad_noise(err, ref_noise):
     """HIP-vs-float64 gradient errors must sit in the same noise band as the fp32 reference's own distance from its
-    float64 run on the same case (flip noise scales with 1/sqrt(#elements), so the band is case dependent):
-    median <= max(1e-3, 8 x ref), 90th percentile <= max(6e-3, 3 x ref), worst <= max(2e-2, 3 x ref)."""
+    float64 run on the same case (flip noise scales with 1/sqrt(#elements), so the band is case dependent).  Bands are
+    ~2x what was measured on MI355X (2x2x32^3, stage 1: median 4.4e-4, p90 2.0e-3, worst 2.95e-3 against the fp32
+    reference's own 3.5e-6 / 1.8e-3 / 2.5e-3; width x2: 7.0e-4 / 1.7e-3 / 2.9e-3 against 9.3e-4 / 2.1e-3 / 3.9e-3), so
+    a 3x regression fails:  median <= max(9e-4, 2 x ref), 90th percentile <= max(4e-3, 2 x ref), worst <= max(6e-3, 2 x ref)."""
     v, r = np.array(list(err.values())), np.array(list(ref_noise.values()))
     stats = (float(np.median(v)), float(np.percentile(v, 90)), float(v.max()))
     ref = (float(np.median(r)), float(np.percentile(r, 90)), float(r.max()))
     print("gradient rel-L2 vs f64 (median, p90, max): HIP %.2e %.2e %.2e | fp32 reference %.2e %.2e %.2e" % (stats + ref))
-    assert stats[0] <= max(1e-3, 8 * ref[0]) and stats[1] <= max(6e-3, 3 * ref[1]) and stats[2] <= max(2e-2, 3 * ref[2]), \
+    assert stats[0] <= max(9e-4, 2 * ref[0]) and stats[1] <= max(4e-3, 2 * ref[1]) and stats[2] <= max(6e-3, 2 * ref[2]), \
         (stats, ref, sorted(err.items(), key=lambda kv: -kv[1])[:6])
 
 
@@ -328,18 +330,19 @@ def test_block_modules_standalone(A, orc):
 
 @pytest.mark.parametrize("dtype", ["bf16"])
 def test_full_size_properties_128(A, orc, dtype):
-    """BASELINE configs[1] shape (per-sample): size-independent properties at 128^3."""
+    """BASELINE configs[1] as benchmarked (4 x 2 x 128^3, bf16): size-independent properties."""
     m = build(A, orc, 2, dtype)
-    x = orc.synthetic_batch(2, (128, 128, 128), 2, seed=12)["image"].cuda()
+    x = orc.synthetic_batch(4, (128, 128, 128), 2, seed=12)["image"].cuda()
     with torch.no_grad():
         p0, p1 = m(x)
         q0, q1 = m(x[1:2])                       # InstanceNorm network: samples are independent
         r0, r1 = m(x)
-    assert p0.shape == p1.shape == (2, 1, 128, 128, 128)
+        assert torch.equal(p1[3:4], m(x[3:4])[1])
+    assert p0.shape == p1.shape == (4, 1, 128, 128, 128)
     assert torch.isfinite(p0).all() and torch.isfinite(p1).all()
     assert torch.equal(p1, r1) and torch.equal(p0, r0)                # deterministic
     assert torch.equal(p1[1:2], q1) and torch.equal(p0[1:2], q0)       # batch independence (eval mode)
-    label = (torch.rand(2, 1, 128, 128, 128, device="cuda") < 0.03).float()
+    label = (torch.rand(4, 1, 128, 128, 128, device="cuda") < 0.03).float()
     e, d = m(x)
     A.fused_stage_loss(1, e, d, label).backward()
     gs = [p.grad for n, p in m.named_parameters() if not n.startswith("dc62.")]
@@ -364,7 +367,9 @@ def test_three_channel_input_takes_the_materialised_x_branch_fp32(A, orc):
     A.fused_stage_loss(1, e, d, b["label"].cuda()).backward()
     for name in ("x33.conv1.weight", "x63.conv1.weight", "x93.conv1.weight", "ec33.conv1.weight"):
         gq, gp = dict(o.named_parameters())[name].grad, dict(m.named_parameters())[name].grad.cpu()
-        assert float((gp - gq).norm() / gq.norm()) < 2e-2, name          # fp32-vs-fp32 flip noise band (see _check_grad_noise)
+        e = float((gp - gq).norm() / gq.norm())
+        print(f"in_channel=3 {name}: rel-L2 vs fp32 oracle {e:.2e}")
+        assert e < 8e-3, name          # fp32-vs-fp32 flip noise band (see _check_grad_noise)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
@@ -384,3 +389,213 @@ def test_gradients_are_bitwise_reproducible(A, orc, dtype):
     assert runs[0][2].keys() == runs[1][2].keys() and len(runs[0][2]) == 116
     for n in runs[0][2]:
         assert torch.equal(runs[0][2][n], runs[1][2][n]), n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: train-mode backward, stage 2, ragged tiles (40^3 / 160^3), bf16 trainability, data-parallel equivalence
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stage", [1, 2])
+def test_train_mode_forward_backward_injected_drop_fp32(A, orc, stage):
+    """DropLayer ACTIVE (every reference training / validation caller runs model.train(): train.py:578,632) with the
+    two scale tensors injected into both implementations: logits, loss and all gradients against the float64 oracle
+    ('enabled with injected mask for one train-mode parity case').  Stage 2 = GUL on both heads
+    (train.py:428-435)."""
+    b = orc.synthetic_batch(2, (32, 32, 32), 2, seed=21)
+    g = torch.Generator().manual_seed(99)
+    d1 = orc.drop_scale_from_uniform(torch.rand(2, 24, 1, 1, 1, generator=g), 24)
+    d2 = orc.drop_scale_from_uniform(torch.rand(2, 12, 1, 1, 1, generator=g), 12)
+    assert int((d1 == 0).sum()) > 0 and int((d2 == 0).sum()) > 0          # some side maps really are dropped
+    o64 = orc.build_oracle(2, 1, 1, seed=0, train=True).double()
+    pe, pd = o64(b["image"].double(), d1.double(), d2.double())
+    l64 = orc.stage_loss(stage, pe, pd, b["label"].double(), b["weight"].double(), b["skel"].double())
+    l64.backward()
+    o32 = orc.build_oracle(2, 1, 1, seed=0, train=True)
+    qe, qd = o32(b["image"], d1, d2)
+    orc.stage_loss(stage, qe, qd, b["label"], b["weight"], b["skel"]).backward()
+    m = build(A, orc, 2, "fp32", train=True)
+    c = {k: v.cuda() for k, v in b.items()}
+    ge, gd = m(c["image"], drop_scales=(d1, d2))
+    assert float((gd.detach().cpu().double() - pd.detach()).abs().max()) < 1e-4
+    assert float((ge.detach().cpu().double() - pe.detach()).abs().max()) < 1e-4
+    loss = A.fused_stage_loss(stage, ge, gd, c["label"], c["weight"], c["skel"])
+    loss.backward()
+    assert abs(float(loss.detach()) - float(l64.detach())) < 1e-5
+    _check_grad_noise(_rel_errors(m, o64), _rel_errors(o32, o64))
+    # a dropped side map contributes nothing: the head weight of a channel dropped in EVERY sample gets a zero gradient
+    dead1 = (d1.reshape(2, 24) == 0).all(0)
+    if bool(dead1.any()):
+        assert float(m.dc0_0.weight.grad.reshape(-1)[dead1.cuda()].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("width", [1, 2])
+def test_ragged_tiles_40_forward_backward_fp32(A, orc, width):
+    """1 x 2 x 40^3: levels 40 / 20 / 10 / 5 -- no extent is a multiple of the 32-voxel x-tile or the 4-voxel y/z
+    tile at the deeper levels (the small analogue of BASELINE configs[4]'s 160^3 = 160 / 80 / 40 / 20)."""
+    m = A.SE_UNet(2, 1, width_mult=width, act_dtype="fp32")
+    m.load_state_dict(orc.deterministic_state_dict(2, 1, width, seed=0))
+    m = m.cuda().eval()
+    o64 = orc.build_oracle(2, 1, width, seed=0).double()
+    o32 = orc.build_oracle(2, 1, width, seed=0)
+    b = orc.synthetic_batch(1, (40, 40, 40), 2, seed=31)
+    pe, pd = o64(b["image"].double())
+    l64 = orc.stage_loss(1, pe, pd, b["label"].double())
+    l64.backward()
+    qe, qd = o32(b["image"])
+    orc.stage_loss(1, qe, qd, b["label"]).backward()
+    ge, gd = m(b["image"].cuda())
+    assert float((gd.detach().cpu().double() - pd.detach()).abs().max()) < 1e-4
+    assert float((ge.detach().cpu().double() - pe.detach()).abs().max()) < 1e-4
+    loss = A.fused_stage_loss(1, ge, gd, b["label"].cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(l64.detach())) < 1e-5
+    _check_grad_noise(_rel_errors(m, o64), _rel_errors(o32, o64))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_config4_shape_160_width2_properties(A, orc, dtype):
+    """BASELINE configs[4]: 2x channel width, 160^3 (levels 160/80/40/20), 2-byte activations: size-independent
+    properties (finite, deterministic, batch independent, gradients for all 116 live tensors), plus agreement of the two
+    2-byte storage modes with each other at the level their mantissas allow."""
+    if dtype == "fp16" and not hasattr(A._lib, "F16"):
+        pytest.skip("fp16 storage mode not built")
+    m = A.SE_UNet(2, 1, width_mult=2, act_dtype=dtype)
+    m.load_state_dict(orc.deterministic_state_dict(2, 1, 2, seed=0))
+    m = m.cuda().eval()
+    b = orc.synthetic_batch(2, (160, 160, 160), 2, seed=41)
+    x, lab = b["image"].cuda(), b["label"].cuda()
+    with torch.no_grad():
+        p0, p1 = m(x)
+        q0, q1 = m(x[1:2])
+    assert p1.shape == (2, 1, 160, 160, 160) and torch.isfinite(p0).all() and torch.isfinite(p1).all()
+    assert torch.equal(p1[1:2], q1) and torch.equal(p0[1:2], q0)
+    e, d = m(x)
+    assert torch.equal(d.detach(), p1)
+    A.fused_stage_loss(1, e, d, lab).backward()
+    gs = [p.grad for n, p in m.named_parameters() if not n.startswith("dc62.")]
+    assert len(gs) == 116 and all(g is not None and torch.isfinite(g).all() for g in gs)
+
+
+def test_bf16_mode_trains_like_fp32_mode(A, orc):
+    """bf16 activation storage is the benchmark dtype; its per-step gradients differ from float64 by tens of percent on
+    the ill-conditioned tensors (test_bf16_mode_no_worse_than_bf16_autocast), so check what matters: 40 AdamW steps
+    (train.py:569: AdamW, here lr 1e-3 so that 40 steps move the loss) on a fixed learnable batch give the same loss
+    curve in bf16 mode as in fp32 mode.  Band: |bf16 - fp32| <= 0.03 at every step on a loss that starts near 1.9 and must
+    fall by at least 0.15 in both modes."""
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 2, 64, 64, 64, generator=g)
+    label = (img[:, 0:1] > 0.97).float()              # learnable from the image; ~3 % foreground like an airway mask
+    x, lab = img.cuda(), label.cuda()
+    curves = {}
+    for dtype in ("fp32", "bf16"):
+        m = build(A, orc, 2, dtype)
+        opt = A.AdamW(m.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(40):
+            opt.zero_grad(set_to_none=True)
+            e, d = m(x)
+            loss = A.fused_stage_loss(1, e, d, lab)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        curves[dtype] = np.array(losses)
+    f, h = curves["fp32"], curves["bf16"]
+    print("loss curve fp32:", np.round(f[::5], 4), "bf16:", np.round(h[::5], 4), "max |diff| %.4f" % np.abs(f - h).max())
+    assert np.isfinite(f).all() and np.isfinite(h).all()
+    assert f[-1] < f[0] - 0.15 and h[-1] < h[0] - 0.15
+    assert np.abs(f - h).max() <= 0.03
+
+
+def _dp_worker(rank, world, port, backend, q):
+    import os as _os
+    import sys as _sys
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                       LOCAL_RANK=str(rank if backend == "nccl" else 0), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    for p_ in (root, _os.path.join(root, "oracle")):
+        if p_ not in _sys.path:
+            _sys.path.insert(0, p_)
+    import torch as _t
+    import torch.distributed as _dist
+    import seunet_amd as _A
+    import seunet_oracle as _orc
+    from seunet_amd import ddp as _ddp
+    try:
+        _ddp.init_from_env(backend)
+        dev = _t.device("cuda", rank if backend == "nccl" else 0)
+        _t.cuda.set_device(dev)
+        b = _orc.synthetic_batch(2, (32, 32, 32), 2, seed=3)
+        m = _A.SE_UNet(2, 1, act_dtype="fp32")
+        m.load_state_dict(_orc.deterministic_state_dict(2, 1, 1, seed=0))
+        m = m.to(dev).eval()
+        x, lab = b["image"][rank:rank + 1].to(dev), b["label"][rank:rank + 1].to(dev)
+        e, d = m(x)
+        loss = _A.fused_stage_loss(1, e, d, lab, group=True)      # global-batch ratio: sums all-reduced first (SURVEY Q8)
+        loss.backward()
+        grads = [p.grad for p in m.parameters() if p.grad is not None]
+        zero_copy = _ddp._flat_view(grads) is not None            # real backward -> one contiguous bucket (ADVICE r1)
+        n = _ddp.allreduce_gradients(m.parameters())
+        out = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+        q.put((rank, float(loss.detach()), bool(zero_copy), int(n), out if rank == 0 else None))
+        _dist.barrier()
+        _dist.destroy_process_group()
+    except Exception as ex:     # report instead of hanging the parent
+        q.put((rank, repr(ex), False, 0, None))
+
+
+def _run_dp_equivalence(A, orc, backend):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000 + (7 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+    assert all(isinstance(r[1], float) for r in res), res
+    # single process, batch 2
+    b = orc.synthetic_batch(2, (32, 32, 32), 2, seed=3)
+    m = build(A, orc, 2, "fp32")
+    e, d = m(b["image"].cuda())
+    loss = A.fused_stage_loss(1, e, d, b["label"].cuda())
+    loss.backward()
+    assert abs(res[0][1] - float(loss.detach())) < 1e-6 and abs(res[1][1] - float(loss.detach())) < 1e-6
+    assert res[0][2] and res[1][2], "gradients of a real backward are not one contiguous bucket"
+    assert res[0][3] == 1_520_314 - 768
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        ref, got = p.grad.cpu().double(), res[0][4][k].double()
+        if k.endswith("conv1.bias"):
+            assert float(got.abs().max()) <= 1e-6
+            continue
+        worst = max(worst, float((got - ref).norm() / max(float(ref.norm()), 1e-30)))
+    print(f"1 GPU x B=2 vs 2 ranks x B=1 ({backend}): worst gradient rel-L2 {worst:.2e}")
+    assert worst < 1e-4
+
+
+def test_data_parallel_two_ranks_equal_one_rank_batch2_gloo_shared_gpu(A, orc):
+    """SURVEY 8(e) exact-sum form on hardware that has ONE GPU: two ranks share cuda:0 and exchange over gloo
+    (loss sums all-reduced before the ratio, train.py:53-57; parameter gradients SUMMED in place in the flat bucket).
+    Must equal the single-process batch-2 step.  Also asserts the zero-copy bucket on a real backward."""
+    _run_dp_equivalence(A, orc, "gloo")
+
+
+def test_data_parallel_two_gpus_equal_one_gpu_batch2_rccl(A, orc):
+    """The same equivalence over RCCL with one GPU per rank (skipped on a single-GPU box)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_dp_equivalence(A, orc, "nccl")
+
+
+def test_second_backward_and_input_grad_fail_clearly(A, orc):
+    m = build(A, orc, 2, "fp32")
+    x = orc.synthetic_batch(1, (16, 16, 16), 2, seed=1)["image"].cuda()
+    e, d = m(x)
+    (e.sum() + d.sum()).backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        (e.sum() + d.sum()).backward()
+    with pytest.raises(NotImplementedError, match="input"):
+        m(x.clone().requires_grad_(True))
