@@ -159,12 +159,32 @@ int seunet_adamw_step(float* const* params, const float* const* grads, float* co
                       const long long* counts, int n_tensors, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, int maximize, seunet_stream_t s);
 
-/* ---- post-processing: double_threshold_iteration, prediction.py:13-37 (= train.py:25-49) -------
- * pred: (h, w, z) float64 probabilities on the device (the overlap-averaged volume, prediction.py:109); out: h*w*z
- * bytes, 1 where the reference's result is 1.0.  Reproduces the reference's single in-place raster-order sweep
- *  bit for bit.  workspace: seunet_dti_workspace_bytes(h, w, z) bytes, caller-owned. */
+/* ---- sliding-window assembly: the data movement of prediction.py:78-109 and of the validation /
+ * test loops train.py:682-691, test.py:151-161 (window table: data.py:731-773), on the device.
+ * volume: (c, x, y, z) f32 NCDHW of ONE case, resident in HBM (prediction.py:77 `x.cuda()`); starts: HOST array of
+ * nwin (xl, yl, zl) triples, nwin <= 64 per call; windows are cube^3 (cube % 4 == 0).
+ *   gather:      out (nwin, c, cube, cube, cube) f32 = volume[:, xl:xl+cube, yl:yl+cube, zl:zl+cube]   (prediction.py:102)
+ *   accumulate:  acc[xl:.., yl:.., zl:..] += sigmoid(logits[k]) in float64, k in list order, no atomics   (:104-106)
+ *   finalize:    out = acc / pred_num, pred_num rebuilt from the per-axis window starts (the windows are a product
+ *                grid) plus dup0 extra copies of window 0 = (xs[0], ys[0], zs[0]) (data.py:764-765)          (:107,109) */
+int seunet_window_gather(const float* volume, int c, int x, int y, int z, int cube, int nwin, const int* starts, float* out,
+                         seunet_stream_t s);
+int seunet_window_accumulate(const float* logits, int apply_sigmoid, int nwin, const int* starts, int cube, double* acc, int x, int y,
+                             int z, seunet_stream_t s);
+int seunet_window_finalize(const double* acc, int x, int y, int z, int cube, int nx, const int* xs, int ny, const int* ys, int nz,
+                           const int* zs, int dup0, double* out, seunet_stream_t s);
+
+/* ---- post-processing: double_threshold_iteration ----------------------------------------------
+ * The reference carries three copies that differ in one line: prediction.py:13-37 keeps pred*255 in float64 (:19);
+ * train.py:25-49 and test.py:18-42 (validation / test) round it to float32 (train.py:31, test.py:24), so values within
+ * a float32 ulp of a threshold classify differently.  pred_dtype selects the copy: SEUNET_DTI_F64 | SEUNET_DTI_F32.
+ * pred: (h, w, z) float64 probabilities on the device (the overlap-averaged volume, prediction.py:109, train.py:693);
+ * out: h*w*z bytes, 1 where the reference's result is 1.0.  Reproduces the reference's single in-place raster-order
+ * sweep bit for bit.  workspace: seunet_dti_workspace_bytes(h, w, z) bytes, caller-owned. */
+#define SEUNET_DTI_F64 0
+#define SEUNET_DTI_F32 1
 size_t seunet_dti_workspace_bytes(int h, int w, int z);
-int seunet_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out,
+int seunet_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, int pred_dtype, unsigned char* out,
                void* workspace, size_t workspace_bytes, seunet_stream_t s);
 
 /* ---- whole network: SE_UNet.forward (SE_UNet.py:181-238) and its backward ------------------------------- */

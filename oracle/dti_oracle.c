@@ -1,7 +1,10 @@
 /* CPU oracle for double_threshold_iteration.  TEST INFRASTRUCTURE ONLY.
  *
- * Plain-C restatement of the reference loop, statement by statement (prediction.py:13-37; the same function is
- * train.py:25-49): pred*255 in float64, bin = pred >= h*255, gbin = copy of bin, then ONE raster-order in-place sweep
+ * Plain-C restatement of the reference loop, statement by statement.  The reference has THREE copies of the function that
+ * differ in one line: prediction.py:19 keeps pred*255 in float64; train.py:31 and test.py:24 (validation / test) round it to
+ * float32 (`np.array(pred*255, dtype=np.float32)`), after which numpy (NEP 50, requirements.txt pins numpy 2.1.3) compares
+ * in float32 with the thresholds h*255, l*255 rounded to float32 -- voxels within a float32 ulp of a threshold classify
+ * differently.  `f32` selects the variant.  Then: bin = pred >= h*255, gbin = copy of bin, ONE raster-order in-place sweep
  * (the `while` compares gbin_pre.all() with gbin.all() after `gbin_pre = gbin` aliased the array, so its body runs
  * exactly once -- SURVEY Q11); a weak voxel (gbin == 0, l*255 <= pred < h*255) is switched on when any of the 26
  * neighbours, indices clamped to the volume (prediction.py:33), is non-zero at that moment.
@@ -17,13 +20,15 @@ static const int NEIGB[26][3] = {   /* prediction.py:14-17, same order */
 static int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
 /* pred: h*w*z float64, out: h*w*z bytes (1 where the reference returns 1.0).  Returns 0, or 1 on allocation failure. */
-int dti_oracle(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out) {
+int dti_oracle(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, int f32, unsigned char* out) {
   const long long n = (long long)h * w * z;
   double* p = (double*)malloc((size_t)n * sizeof(double));
   if (!p) return 1;
-  const double hs = h_thresh * 255, ls = l_thresh * 255;
+  double hs = h_thresh * 255, ls = l_thresh * 255;
+  if (f32) { hs = (double)(float)hs; ls = (double)(float)ls; }   /* weak python scalars take the array's float32 */
   for (long long i = 0; i < n; ++i) {
     p[i] = pred[i] * 255;
+    if (f32) p[i] = (double)(float)p[i];                         /* train.py:31 / test.py:24 */
     out[i] = p[i] >= hs ? 1 : 0;
   }
   for (int i = 0; i < h; ++i)

@@ -17,14 +17,16 @@ def _load():
             subprocess.run(["make", "-C", HERE], check=True)
         _LIB = C.CDLL(path)
         _LIB.dti_oracle.restype = C.c_int
-        _LIB.dti_oracle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        _LIB.dti_oracle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
     return _LIB
 
 
-def double_threshold_iteration(pred: np.ndarray, h_thresh: float, l_thresh: float) -> np.ndarray:
-    """prediction.py:13-37 on a (h, w, z) array; returns float64 zeros/ones like the reference."""
+def double_threshold_iteration(pred: np.ndarray, h_thresh: float, l_thresh: float, pred_dtype: str = "float64") -> np.ndarray:
+    """prediction.py:13-37 (pred_dtype "float64") or train.py:25-49 / test.py:18-42 (pred_dtype "float32": pred*255 is
+    rounded to float32 first) on a (h, w, z) array; returns float64 zeros/ones like the reference."""
     p = np.ascontiguousarray(pred, dtype=np.float64)
     out = np.empty(p.shape, dtype=np.uint8)
-    if _load().dti_oracle(p.ctypes.data, p.shape[0], p.shape[1], p.shape[2], float(h_thresh), float(l_thresh), out.ctypes.data):
+    f32 = {"float64": 0, "float32": 1}[pred_dtype]
+    if _load().dti_oracle(p.ctypes.data, p.shape[0], p.shape[1], p.shape[2], float(h_thresh), float(l_thresh), f32, out.ctypes.data):
         raise MemoryError("dti_oracle")
     return out.astype(np.float64)

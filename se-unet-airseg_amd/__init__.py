@@ -10,8 +10,8 @@ from .SE_UNet import CATConv, DropLayer, SE_UNet, SSEConv, SSEConv2, get_model
 from .optim import AdamW
 from .postprocess import double_threshold_iteration, postprocess_prediction, zero_borders
 from .losses import atr_loss, dice_loss, fused_logit_loss, fused_stage_loss, general_union_loss_lib
-from .sliding_window import sliding_window_predict, two_channel, window_starts
+from .sliding_window import sliding_window_predict, sliding_window_validate, two_channel, window_starts, window_table
 
 __all__ = ["SE_UNet", "SSEConv", "SSEConv2", "CATConv", "DropLayer", "get_model", "dice_loss",
            "general_union_loss_lib", "atr_loss", "fused_logit_loss", "fused_stage_loss",
-           "sliding_window_predict", "two_channel", "window_starts", "AdamW", "double_threshold_iteration", "postprocess_prediction", "zero_borders"]
+           "sliding_window_predict", "sliding_window_validate", "two_channel", "window_starts", "window_table", "AdamW", "double_threshold_iteration", "postprocess_prediction", "zero_borders"]

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("SEUNET_LIB") or os.path.join(_HERE, "libseunet_hip.so
 F32, BF16 = 0, 1
 CONV_MFMA, CONV_NAIVE = 0, 1
 LOSS_NSUMS = 7
+DTI_F64, DTI_F32 = 0, 1
 
 
 class Dims(C.Structure):
@@ -71,8 +72,11 @@ PROTOTYPES = {
     "seunet_cat_epilogue_fwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, Dims, _vp]),
     "seunet_cat_epilogue_bwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),
     "seunet_cat_xgrad_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "seunet_window_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _ip, _vp, _vp]),
+    "seunet_window_accumulate": (_i, [_vp, _i, _i, _ip, _i, _vp, _i, _i, _i, _vp]),
+    "seunet_window_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _ip, _i, _ip, _i, _ip, _i, _vp, _vp]),
     "seunet_dti_workspace_bytes": (_sz, [_i, _i, _i]),
-    "seunet_dti": (_i, [_vp, _i, _i, _i, C.c_double, C.c_double, _vp, _vp, _sz, _vp]),
+    "seunet_dti": (_i, [_vp, _i, _i, _i, C.c_double, C.c_double, _i, _vp, _vp, _sz, _vp]),
     "seunet_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _i, _vp]),
     "seunet_net_param_count": (_i, [C.POINTER(NetDesc)]),
     "seunet_net_param_info": (_i, [C.POINTER(NetDesc), _i, C.c_char_p, _i, _ip, _ip]),

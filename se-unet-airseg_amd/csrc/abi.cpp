@@ -206,13 +206,26 @@ int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_
   return launch_cat_xgrad_reduce(xw_partial, records, c, in_channel, dw, S(s));
 }
 
+int seunet_window_gather(const float* volume, int c, int x, int y, int z, int cube, int nwin, const int* starts, float* out,
+                         seunet_stream_t s) {
+  return launch_window_gather(volume, c, x, y, z, cube, nwin, starts, out, S(s));
+}
+int seunet_window_accumulate(const float* logits, int apply_sigmoid, int nwin, const int* starts, int cube, double* acc, int x, int y,
+                             int z, seunet_stream_t s) {
+  return launch_window_accumulate(logits, apply_sigmoid, nwin, starts, cube, acc, x, y, z, S(s));
+}
+int seunet_window_finalize(const double* acc, int x, int y, int z, int cube, int nx, const int* xs, int ny, const int* ys, int nz,
+                           const int* zs, int dup0, double* out, seunet_stream_t s) {
+  return launch_window_finalize(acc, x, y, z, cube, nx, xs, ny, ys, nz, zs, dup0, out, S(s));
+}
+
 size_t seunet_dti_workspace_bytes(int h, int w, int z) {
   if (h < 1 || w < 1 || z < 1) { fail("dti_workspace_bytes: bad dimensions"); return 0; }
   return dti_workspace_bytes(h, w, z);
 }
-int seunet_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out,
+int seunet_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, int pred_dtype, unsigned char* out,
                void* workspace, size_t workspace_bytes, seunet_stream_t s) {
-  return launch_dti(pred, h, w, z, h_thresh, l_thresh, out, workspace, workspace_bytes, S(s));
+  return launch_dti(pred, h, w, z, h_thresh, l_thresh, pred_dtype, out, workspace, workspace_bytes, S(s));
 }
 
 int seunet_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,

@@ -1,4 +1,7 @@
-// double_threshold_iteration on the GPU (reference prediction.py:13-37, same function at train.py:25-49).
+// double_threshold_iteration on the GPU.  The reference has three copies that differ in ONE line:
+// prediction.py:13-37 keeps pred*255 in float64 (:19); train.py:25-49 and test.py:18-42 (validation / test) round it to
+// float32 (train.py:31, test.py:24), so that numpy compares in float32 against thresholds rounded to float32 (NEP 50;
+// requirements.txt pins numpy 2.1.3).  Voxels within a float32 ulp of a threshold classify differently: `f32` selects the copy.
 //
 // What the reference computes: pred*255 is thresholded into strong (>= h*255) and weak (>= l*255, < h*255)
 // voxels; gbin starts as the strong mask; then ONE in-place raster-order sweep (i outer, k inner -- the `while` body runs
@@ -22,7 +25,7 @@ typedef unsigned long long u64;
 
 // strong / weak masks, bit-packed along k.  One thread per (row, word).
 __global__ void __launch_bounds__(256)
-dti_pack_kernel(const double* __restrict__ pred, long long rows, int z, int nw, double hs, double ls,
+dti_pack_kernel(const double* __restrict__ pred, long long rows, int z, int nw, double hs, double ls, int f32,
                 u64* __restrict__ strong, u64* __restrict__ weak) {
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
   if (idx >= rows * nw) return;
@@ -32,7 +35,8 @@ dti_pack_kernel(const double* __restrict__ pred, long long rows, int z, int nw, 
   u64 s = 0, w = 0;
   const int k1 = (m * 64 + 64 < z) ? m * 64 + 64 : z;
   for (int k = m * 64; k < k1; ++k) {
-    const double v = p[k] * 255.0;                 // (pred*255 in float64, prediction.py:19)
+    double v = p[k] * 255.0;                       // (pred*255 in float64, prediction.py:19)
+    if (f32) v = (double)(float)v;                 // np.array(pred*255, dtype=np.float32), train.py:31 / test.py:24
     const bool st = v >= hs;
     const bool wk = !st && v >= ls;                // pred < h*255 and pred >= l*255 (prediction.py:28)
     s |= (u64)st << (k & 63);
@@ -104,16 +108,18 @@ size_t dti_workspace_bytes(int h, int w, int z) {
   return (size_t)(2 * (long long)h * w * nw * 8);
 }
 
-int launch_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out,
+int launch_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, int pred_dtype, unsigned char* out,
                void* workspace, size_t ws_bytes, hipStream_t s) {
   SEUNET_CHECK(pred && out && workspace && h >= 1 && w >= 1 && z >= 1, "dti: bad argument");
+  SEUNET_CHECK(pred_dtype == 0 || pred_dtype == 1, "dti: pred_dtype %d (0 = float64 copy of prediction.py, 1 = float32 copy of train.py / test.py)", pred_dtype);
   SEUNET_CHECK(ws_bytes >= dti_workspace_bytes(h, w, z), "dti: workspace too small");
   const int nw = (z + 63) / 64;
   const long long rows = (long long)h * w;
   u64* g = reinterpret_cast<u64*>(workspace);
   u64* weak = g + rows * nw;
-  const double hs = h_thresh * 255.0, ls = l_thresh * 255.0;   // (h_thresh*255, l_thresh*255 in float64, prediction.py:20,28)
-  dti_pack_kernel<<<(unsigned)((rows * nw + 255) / 256), 256, 0, s>>>(pred, rows, z, nw, hs, ls, g, weak);
+  double hs = h_thresh * 255.0, ls = l_thresh * 255.0;         // (h_thresh*255, l_thresh*255 in float64, prediction.py:20,28)
+  if (pred_dtype == 1) { hs = (double)(float)hs; ls = (double)(float)ls; }   // weak python scalars adopt the array's float32
+  dti_pack_kernel<<<(unsigned)((rows * nw + 255) / 256), 256, 0, s>>>(pred, rows, z, nw, hs, ls, pred_dtype, g, weak);
   dti_sweep_kernel<<<1, 1024, 0, s>>>(g, weak, h, w, nw);
   dti_unpack_kernel<<<(unsigned)((rows * z + 255) / 256), 256, 0, s>>>(g, rows, z, nw, out);
   SEUNET_LAUNCH_CHECK();

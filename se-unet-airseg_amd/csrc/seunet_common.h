@@ -256,8 +256,14 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, 
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate,
                          Dims din, hipStream_t s);
 int launch_multi_zero(float* const* ptrs, const int* counts, int n, hipStream_t s);
+// sliding-window assembly (window.hip)
+int launch_window_gather(const float* vol, int C, int X, int Y, int Z, int cube, int nwin, const int* starts, float* out, hipStream_t s);
+int launch_window_accumulate(const float* logits, int apply_sigmoid, int nwin, const int* starts, int cube, double* acc, int X, int Y,
+                             int Z, hipStream_t s);
+int launch_window_finalize(const double* acc, int X, int Y, int Z, int cube, int nx, const int* xs, int ny, const int* ys, int nz,
+                           const int* zs, int dup0, double* out, hipStream_t s);
 size_t dti_workspace_bytes(int h, int w, int z);
-int launch_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, unsigned char* out,
+int launch_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, int pred_dtype, unsigned char* out,
                void* workspace, size_t ws_bytes, hipStream_t s);
 int launch_adamw(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const long long* counts, int n, double lr, double beta1, double beta2, double eps, double weight_decay,

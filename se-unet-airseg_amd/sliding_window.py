@@ -1,10 +1,15 @@
-"""Whole-volume sliding-window inference (reference prediction.py:39-49, 65-109; data.py:731-773)."""
+"""Whole-volume sliding-window inference (reference prediction.py:39-49, 65-109; validation form train.py:631-699 with
+the window table of data.py:731-773).  Window gathering, the float64 overlap accumulation and the final division run
+on the device (csrc/window.hip through ``seunet_window_*``); there is one D2H copy of the finished volume, where the
+reference copies 8 MB per window (prediction.py:104-107)."""
 from __future__ import annotations
 
-from typing import List
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+from . import _lib
 
 
 def two_channel(data: np.ndarray):
@@ -23,24 +28,74 @@ def window_starts(dim: int, cube: int = 128, step: int = 64) -> List[int]:
     return [min(step * i, dim - cube) for i in range(n)]
 
 
-@torch.no_grad()
-def sliding_window_predict(model, x: torch.Tensor, cube: int = 128, step: int = 64, batch: int = 1) -> np.ndarray:
-    """x: (1, C, X, Y, Z) on the GPU.  Returns the overlap-averaged sigmoid(pred1) volume (float64 numpy,
-    like the reference's host accumulators) -- accumulated on the device in float64, one D2H at the end
-    instead of the reference's 8 MB copy per window (prediction.py:104-107)."""
-    if not x.is_cuda:
-        raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
-    _, _, X, Y, Z = x.shape
-    acc = torch.zeros((X, Y, Z), dtype=torch.float64, device=x.device)
-    cnt = torch.zeros((X, Y, Z), dtype=torch.float64, device=x.device)
+def window_table(shape: Sequence[int], cube: int = 128, step: int = 64, pad_to_batch: Optional[int] = None
+                 ) -> List[Tuple[int, int, int]]:
+    """All (xl, yl, zl) window origins in the reference's loop order (x outer, z inner: prediction.py:83-100).
+    ``pad_to_batch``: append copies of window 0 until the count is a multiple of it (``SegValCropData.crop_pos``,
+    data.py:764-765 -- the validation / test loops then run AND accumulate those copies)."""
+    X, Y, Z = shape
     pos = [(a, b, c) for a in window_starts(X, cube, step) for b in window_starts(Y, cube, step)
            for c in window_starts(Z, cube, step)]
-    for i in range(0, len(pos), batch):
-        chunk = pos[i:i + batch]
-        xin = torch.cat([x[:, :, a:a + cube, b:b + cube, c:c + cube] for a, b, c in chunk], 0)
-        _, p = model(xin)
-        p = torch.sigmoid(p).double()
-        for k, (a, b, c) in enumerate(chunk):
-            acc[a:a + cube, b:b + cube, c:c + cube] += p[k, 0]
-            cnt[a:a + cube, b:b + cube, c:c + cube] += 1
-    return (acc / cnt).cpu().numpy()
+    if pad_to_batch:
+        while len(pos) % pad_to_batch:
+            pos.append(pos[0])
+    return pos
+
+
+def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_dup: int) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
+    if x.dim() != 5 or x.shape[0] != 1:
+        raise ValueError(f"expected one case (1, C, X, Y, Z), got {tuple(x.shape)}")
+    lib = _lib.load()
+    x = x.contiguous().float()
+    _, C_, X, Y, Z = x.shape
+    max_call = 64                                       # windows per native call (kernel-argument table)
+    with torch.cuda.device(x.device):
+        st = _lib.stream_ptr()
+        acc = torch.zeros((X, Y, Z), dtype=torch.float64, device=x.device)
+        for i in range(0, len(pos), batch):
+            chunk = pos[i:i + batch]
+            xin = torch.empty((len(chunk), C_, cube, cube, cube), dtype=torch.float32, device=x.device)
+            for j in range(0, len(chunk), max_call):
+                sub = chunk[j:j + max_call]
+                arr = _lib.int_array([v for p in sub for v in p])
+                _lib.check(lib.seunet_window_gather(x.data_ptr(), C_, X, Y, Z, cube, len(sub), arr, xin[j:].data_ptr(), st), "window_gather")
+            _, p = model(xin)                           # logits of the decoder head (prediction.py:103 `p0, p = model(...)`)
+            p = p.contiguous()
+            for j in range(0, len(chunk), max_call):
+                sub = chunk[j:j + max_call]
+                arr = _lib.int_array([v for q in sub for v in q])
+                _lib.check(lib.seunet_window_accumulate(p[j:].data_ptr(), 1, len(sub), arr, cube, acc.data_ptr(), X, Y, Z, st),
+                           "window_accumulate")
+        xs, ys, zs = window_starts(X, cube, step), window_starts(Y, cube, step), window_starts(Z, cube, step)
+        out = torch.empty_like(acc)
+        _lib.check(lib.seunet_window_finalize(acc.data_ptr(), X, Y, Z, cube, len(xs), _lib.int_array(xs), len(ys), _lib.int_array(ys),
+                                              len(zs), _lib.int_array(zs), n_dup, out.data_ptr(), st), "window_finalize")
+    return out
+
+
+@torch.no_grad()
+def sliding_window_predict(model, x: torch.Tensor, cube: int = 128, step: int = 64, batch: int = 1,
+                           return_tensor: bool = False):
+    """prediction.py:78-109.  x: (1, C, X, Y, Z) on the GPU.  Returns the overlap-averaged sigmoid(pred1) volume as
+    float64 numpy (like the reference's host accumulators), or the float64 CUDA tensor with ``return_tensor=True`` (what
+    ``double_threshold_iteration`` takes next, prediction.py:110).  ``batch`` windows go through the network per call
+    (the reference uses 1; results are identical in eval mode because InstanceNorm is per sample)."""
+    pos = window_table(x.shape[2:], cube, step)
+    out = _assemble(model, x, pos, cube, step, batch, 0)
+    return out if return_tensor else out.cpu().numpy()
+
+
+@torch.no_grad()
+def sliding_window_validate(model, x: torch.Tensor, batch: int = 24, cube: int = 128, step: int = 64,
+                            return_tensor: bool = False):
+    """The validation / test form of the loop (train.py:682-693 with ``SegValCropData``, data.py:731-773; test.py:151-161
+    with batch 8): the window list is padded with copies of window 0 to a multiple of ``batch`` and the copies are run and
+    accumulated like any other window.  The reference runs this loop under ``model.train()`` (train.py:632):
+    DropLayer is then active, its scale depends on the batch size, and each copy of window 0 gets its own draw -- call
+    ``model.train()`` / ``model.eval()`` yourself, as the reference does."""
+    pos = window_table(x.shape[2:], cube, step, pad_to_batch=batch)
+    n_real = len(window_table(x.shape[2:], cube, step))
+    out = _assemble(model, x, pos, cube, step, batch, len(pos) - n_real)
+    return out if return_tensor else out.cpu().numpy()

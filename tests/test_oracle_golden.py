@@ -165,3 +165,19 @@ def test_dti_oracle_matches_reference_function_fixture(golden_dir):
     assert out[1, 1].tolist() == [0, 0, 0, 0, 0, 0, 0, 0, 1, 1]
     chain[1, 1, 9] = 0.45; chain[1, 1, 0] = 0.9          # fed from the near end: the whole chain switches on
     assert do.double_threshold_iteration(chain, 0.5, 0.4)[1, 1].sum() == 10
+
+
+def test_dti_oracle_float32_copies_match_reference_fixture(golden_dir):
+    """The float32 copies of the function (train.py:25-49, test.py:18-42: pred*255 rounded to float32) differ from
+    prediction.py's float64 copy on voxels within a float32 ulp of a threshold; fixture from the reference's own copies."""
+    import dti_oracle as do
+    d = _load(golden_dir, "dti_known_f32.npz")
+    differ = 0
+    for c in range(int(d["n"])):
+        v, h, l = d[f"pred_{c}"], float(d[f"h_{c}"]), float(d[f"l_{c}"])
+        got32 = do.double_threshold_iteration(v, h, l, "float32").astype(np.uint8)
+        got64 = do.double_threshold_iteration(v, h, l, "float64").astype(np.uint8)
+        np.testing.assert_array_equal(got32, d[f"out_{c}"])
+        np.testing.assert_array_equal(got64, d[f"out64_{c}"])
+        differ += int((got32 != got64).sum())
+    assert differ > 100

@@ -24,6 +24,22 @@ def test_fixture_parity(golden_dir):
         np.testing.assert_array_equal(got.astype(np.uint8), d[f"out_{c}"])
 
 
+def test_fixture_parity_float32_copies(golden_dir):
+    """train.py:25-49 / test.py:18-42 (pred*255 rounded to float32): fixture from those copies, including volumes with
+    voxels within a float32 ulp of the thresholds, on which the float64 copy (prediction.py) gives a different answer."""
+    A = _A()
+    d = np.load(os.path.join(golden_dir, "dti_known_f32.npz"))
+    differ = 0
+    for c in range(int(d["n"])):
+        v, h, l = d[f"pred_{c}"], float(d[f"h_{c}"]), float(d[f"l_{c}"])
+        got32 = A.double_threshold_iteration(v, h, l, pred_dtype="float32").astype(np.uint8)
+        got64 = A.double_threshold_iteration(v, h, l, pred_dtype="float64").astype(np.uint8)
+        np.testing.assert_array_equal(got32, d[f"out_{c}"])
+        np.testing.assert_array_equal(got64, d[f"out64_{c}"])
+        differ += int((got32 != got64).sum())
+    assert differ > 0
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 1, 200), (5, 7, 63), (5, 7, 64), (5, 7, 65), (17, 3, 129), (3, 40, 191),
                                    (40, 3, 64), (33, 31, 257), (64, 64, 64), (128, 128, 128)])
 @pytest.mark.parametrize("kind", ["noise", "smooth"])
@@ -37,10 +53,11 @@ def test_against_c_oracle(shape, kind):
             v = (v + np.roll(v, 1, ax) + np.roll(v, -1, ax)) / 3.0
         v = (v - v.min()) / max(v.max() - v.min(), 1e-9)
     for h, l in ((0.5, 0.4), (0.62, 0.37)):
-        want = do.double_threshold_iteration(v, h, l)
-        got = A.double_threshold_iteration(torch.from_numpy(v).cuda(), h, l)
-        assert got.dtype == torch.uint8 and got.is_cuda
-        np.testing.assert_array_equal(got.cpu().numpy(), want.astype(np.uint8))
+        for pd in ("float64", "float32"):
+            want = do.double_threshold_iteration(v, h, l, pd)
+            got = A.double_threshold_iteration(torch.from_numpy(v).cuda(), h, l, pred_dtype=pd)
+            assert got.dtype == torch.uint8 and got.is_cuda
+            np.testing.assert_array_equal(got.cpu().numpy(), want.astype(np.uint8))
 
 
 def test_thresholds_exactly_on_the_boundary():
@@ -88,5 +105,5 @@ def test_bad_arguments_report_errors():
     assert lib.seunet_dti_workspace_bytes(0, 4, 4) == 0
     out = torch.empty(8, dtype=torch.uint8, device="cuda")
     p = torch.zeros(8, dtype=torch.float64, device="cuda")
-    assert lib.seunet_dti(p.data_ptr(), 2, 2, 2, 0.5, 0.4, out.data_ptr(), out.data_ptr(), 1, None) != 0   # workspace too small
+    assert lib.seunet_dti(p.data_ptr(), 2, 2, 2, 0.5, 0.4, 0, out.data_ptr(), out.data_ptr(), 1, None) != 0   # workspace too small
     assert "workspace" in A._lib.last_error()
