@@ -159,6 +159,30 @@ int seunet_adamw_step(float* const* params, const float* const* grads, float* co
                       const long long* counts, int n_tensors, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, int maximize, seunet_stream_t s);
 
+/* ---- input pipeline: one resident case -> the tensors of a training step, in one launch ------------------
+ * Replaces, for a mini-batch of crops: crop extraction (data.py:645-664, :85-252), the two HU windows (data.py:667-677,
+ * :286-299, :775-784 = prediction.py:39-49), (mask > 0) (data.py:675), weight ** (U + 2) * label + (1 - label)
+ * (data.py:701, :389, :561) and the flip / rotate augmentation (data.py:40-67), and writes the layout train.py:582-592
+ * builds: data_out (ncrop, 2, cube^3) [2048-window, 1500-window], label_out / weight_out / skel_out (ncrop, 1, cube^3), f32.
+ * img: (d, h, w) HU (= file value - 1024, data.py:692), int16 or float32; label / skeleton: uint8 or NULL; weight: float16
+ * (the LIB maps, lib_weight.py:50) / float32 / float64 or NULL.  starts: HOST (z, y, x) per crop; aug: HOST code per crop
+ * (NULL = none): bit k = source axis k reversed, bit 3 = source axes 1 and 2 fed by output axes 2 and 1 (random_flip then
+ * random_rotate composed; all random draws stay with the caller).  weight_exponent = U + 2.  f64_math: 1 = true division
+ * in float64 then one rounding (int crops, data.py:286-299; prediction.py:40), 0 = float32 division (data.py:667-677).
+ * cube % 32 == 0, ncrop <= 32 per call. */
+#define SEUNET_IMG_I16 0
+#define SEUNET_IMG_F32 1
+#define SEUNET_W_F16 0
+#define SEUNET_W_F32 1
+#define SEUNET_W_F64 2
+int seunet_crop_batch(const void* img, int img_dtype, const unsigned char* label, const void* weight, int weight_dtype,
+                      const unsigned char* skeleton, int d, int h, int w, int cube, int ncrop, const int* starts, const int* aug,
+                      double weight_exponent, int f64_math, float* data_out, float* label_out, float* weight_out, float* skel_out,
+                      seunet_stream_t s);
+/* whole-volume network input of the inference / validation loops (prediction.py:39-49,71-75; data.py:775-784,796-798):
+ * out (2, nvox) f32 = [2048-window | 1500-window] */
+int seunet_hu_two_channel(const void* img, int img_dtype, long long nvox, int f64_math, float* out, seunet_stream_t s);
+
 /* ---- sliding-window assembly: the data movement of prediction.py:78-109 and of the validation /
  * test loops train.py:682-691, test.py:151-161 (window table: data.py:731-773), on the device.
  * volume: (c, x, y, z) f32 NCDHW of ONE case, resident in HBM (prediction.py:77 `x.cuda()`); starts: HOST array of

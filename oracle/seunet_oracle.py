@@ -366,6 +366,41 @@ def sliding_window_predict(model: nn.Module, x: torch.Tensor, cube: int = 128, s
     return np.squeeze(acc / cnt)
 
 
+def validation_window_table(shape: Sequence[int], batch: int, cube: int = 128, step: int = 64
+                            ) -> List[Tuple[int, int, int, int, int, int]]:
+    """SegValCropData.crop_pos (data.py:731-773): [xl, xr, yl, yr, zl, zr] for every window, x outer / z inner, then
+    copies of the FIRST window appended until the count is a multiple of the batch size (data.py:764-765)."""
+    tmp = []
+    for xl in window_starts(shape[0], cube, step):
+        for yl in window_starts(shape[1], cube, step):
+            for zl in window_starts(shape[2], cube, step):
+                tmp.append((xl, xl + cube, yl, yl + cube, zl, zl + cube))
+    while len(tmp) % batch != 0:
+        tmp.append(tmp[0])
+    return tmp
+
+
+def sliding_window_validate(model: nn.Module, x: torch.Tensor, batch: int, cube: int = 128, step: int = 64) -> np.ndarray:
+    """The validation / test form of the loop (train.py:682-693; test.py:151-161): batches of ``batch`` windows in table
+    order (DataLoader(batch_size=batch, shuffle=False), train.py:181-185), ``pred[...] += sigmoid(p)[i]`` and
+    ``pred_num[...] += 1`` for every entry of the padded table -- the copies of window 0 included -- then the division.
+    The caller sets the mode; the reference runs it under ``model.train()`` (train.py:632), DropLayer active."""
+    _, _, X, Y, Z = x.shape
+    pos = validation_window_table((X, Y, Z), batch, cube, step)
+    pred = np.zeros((1, 1, X, Y, Z))
+    pred_num = np.zeros(pred.shape)
+    with torch.no_grad():
+        for i in range(0, len(pos), batch):
+            chunk = pos[i:i + batch]
+            xb = torch.cat([x[:, :, xl:xr, yl:yr, zl:zr] for xl, xr, yl, yr, zl, zr in chunk], 0)
+            _, p = model(xb)
+            p = torch.sigmoid(p).cpu().numpy()
+            for k, (xl, xr, yl, yr, zl, zr) in enumerate(chunk):
+                pred[0, :, xl:xr, yl:yr, zl:zr] += p[k]
+                pred_num[0, :, xl:xr, yl:yr, zl:zr] += 1
+    return np.squeeze(pred / pred_num)
+
+
 def build_oracle(in_channel=2, n_classes=1, width_mult=1, seed=0, train=False) -> OracleSEUNet:
     m = OracleSEUNet(in_channel, n_classes, width_mult)
     m.load_state_dict(deterministic_state_dict(in_channel, n_classes, width_mult, seed))

@@ -72,6 +72,8 @@ PROTOTYPES = {
     "seunet_cat_epilogue_fwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, Dims, _vp]),
     "seunet_cat_epilogue_bwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),
     "seunet_cat_xgrad_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "seunet_crop_batch": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _ip, C.c_double, _i, _vp, _vp, _vp, _vp, _vp]),
+    "seunet_hu_two_channel": (_i, [_vp, _i, _ll, _i, _vp, _vp]),
     "seunet_window_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _ip, _vp, _vp]),
     "seunet_window_accumulate": (_i, [_vp, _i, _i, _ip, _i, _vp, _i, _i, _i, _vp]),
     "seunet_window_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _ip, _i, _ip, _i, _ip, _i, _vp, _vp]),

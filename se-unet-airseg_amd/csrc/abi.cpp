@@ -206,6 +206,17 @@ int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_
   return launch_cat_xgrad_reduce(xw_partial, records, c, in_channel, dw, S(s));
 }
 
+int seunet_crop_batch(const void* img, int img_dtype, const unsigned char* label, const void* weight, int weight_dtype,
+                      const unsigned char* skeleton, int d, int h, int w, int cube, int ncrop, const int* starts, const int* aug,
+                      double weight_exponent, int f64_math, float* data_out, float* label_out, float* weight_out, float* skel_out,
+                      seunet_stream_t s) {
+  return launch_crop_batch(img, img_dtype, label, weight, weight_dtype, skeleton, d, h, w, cube, ncrop, starts, aug, weight_exponent,
+                           f64_math, data_out, label_out, weight_out, skel_out, S(s));
+}
+int seunet_hu_two_channel(const void* img, int img_dtype, long long nvox, int f64_math, float* out, seunet_stream_t s) {
+  return launch_hu_two_channel(img, img_dtype, nvox, f64_math, out, S(s));
+}
+
 int seunet_window_gather(const float* volume, int c, int x, int y, int z, int cube, int nwin, const int* starts, float* out,
                          seunet_stream_t s) {
   return launch_window_gather(volume, c, x, y, z, cube, nwin, starts, out, S(s));

@@ -256,6 +256,12 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, 
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate,
                          Dims din, hipStream_t s);
 int launch_multi_zero(float* const* ptrs, const int* counts, int n, hipStream_t s);
+// input pipeline (pipeline.hip)
+int launch_crop_batch(const void* img, int img_dtype, const unsigned char* label, const void* weight, int w_dtype,
+                      const unsigned char* skel, int D, int H, int W, int cube, int ncrop, const int* starts, const int* aug,
+                      double weight_exponent, int f64_math, float* data_out, float* label_out, float* weight_out, float* skel_out,
+                      hipStream_t s);
+int launch_hu_two_channel(const void* img, int img_dtype, long long nvox, int f64_math, float* out, hipStream_t s);
 // sliding-window assembly (window.hip)
 int launch_window_gather(const float* vol, int C, int X, int Y, int Z, int cube, int nwin, const int* starts, float* out, hipStream_t s);
 int launch_window_accumulate(const float* logits, int apply_sigmoid, int nwin, const int* starts, int cube, double* acc, int X, int Y,

@@ -600,3 +600,84 @@ def test_second_backward_and_input_grad_fail_clearly(A, orc):
         (e.sum() + d.sum()).backward()
     with pytest.raises(NotImplementedError, match="input"):
         m(x.clone().requires_grad_(True))
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_validation_form_window_loop_matches_oracle(A, orc, train):
+    """train.py:682-693 / data.py:731-773: batches of windows, table padded with copies of window 0 that are run and
+    accumulated too.  12 windows of 32^3 in batches of 5 -> 3 copies of window 0.  In train mode (what the reference's validation runs,
+    train.py:632) DropLayer draws from the CPU generator once per batch in both implementations."""
+    m = build(A, orc, 2, "fp32", train=train)
+    o = orc.build_oracle(2, 1, 1, seed=0, train=train)
+    x = orc.synthetic_batch(1, (40, 48, 56), 2, seed=17)["image"]
+    assert len(orc.validation_window_table((40, 48, 56), 5, 32, 16)) == 15 and len(A.window_table((40, 48, 56), 32, 16, 5)) == 15
+    torch.manual_seed(77)
+    got = A.sliding_window_validate(m, x.cuda(), batch=5, cube=32, step=16)
+    torch.manual_seed(77)
+    ref = orc.sliding_window_validate(o, x, batch=5, cube=32, step=16)
+    assert got.shape == ref.shape == (40, 48, 56) and got.dtype == np.float64
+    err = float(np.abs(got - ref).max())
+    print(f"validation-form assembly (train={train}): max |diff| {err:.2e}")
+    assert err < FP32_ATOL
+
+
+def test_window_kernels_exact_bookkeeping(A):
+    """gather / accumulate / finalize against numpy on integer-valued data: indices, order and counts are exact."""
+    lib = A._lib.load()
+    rng = np.random.default_rng(3)
+    X, Y, Z, cube, C_ = 20, 16, 28, 8, 2
+    vol = torch.from_numpy(rng.integers(-50, 50, (C_, X, Y, Z)).astype(np.float32)).cuda()
+    pos = A.window_table((X, Y, Z), cube, 6, pad_to_batch=7)
+    n_real = len(A.window_table((X, Y, Z), cube, 6))
+    starts = A._lib.int_array([v for p in pos[:5] for v in p])
+    out = torch.empty((5, C_, cube, cube, cube), dtype=torch.float32, device="cuda")
+    A._lib.check(lib.seunet_window_gather(vol.data_ptr(), C_, X, Y, Z, cube, 5, starts, out.data_ptr(), None))
+    for k, (a, b, c) in enumerate(pos[:5]):
+        assert torch.equal(out[k], vol[:, a:a + cube, b:b + cube, c:c + cube])
+    acc = torch.zeros((X, Y, Z), dtype=torch.float64, device="cuda")
+    ref, cnt = np.zeros((X, Y, Z)), np.zeros((X, Y, Z))
+    vals = torch.from_numpy(rng.integers(0, 9, (len(pos), 1, cube, cube, cube)).astype(np.float32)).cuda()
+    for i in range(0, len(pos), 7):
+        chunk = pos[i:i + 7]
+        A._lib.check(lib.seunet_window_accumulate(vals[i:].data_ptr(), 0, len(chunk), A._lib.int_array([v for p in chunk for v in p]),
+                                                  cube, acc.data_ptr(), X, Y, Z, None))
+        for k, (a, b, c) in enumerate(chunk):
+            ref[a:a + cube, b:b + cube, c:c + cube] += vals[i + k, 0].cpu().numpy()
+            cnt[a:a + cube, b:b + cube, c:c + cube] += 1
+    assert np.array_equal(acc.cpu().numpy(), ref)
+    xs, ys, zs = (A.window_starts(d, cube, 6) for d in (X, Y, Z))
+    fin = torch.empty_like(acc)
+    A._lib.check(lib.seunet_window_finalize(acc.data_ptr(), X, Y, Z, cube, len(xs), A._lib.int_array(xs), len(ys), A._lib.int_array(ys),
+                                            len(zs), A._lib.int_array(zs), len(pos) - n_real, fin.data_ptr(), None))
+    assert np.array_equal(fin.cpu().numpy(), ref / cnt)
+    bad = A._lib.int_array([X - cube + 1, 0, 0])
+    assert lib.seunet_window_gather(vol.data_ptr(), C_, X, Y, Z, cube, 1, bad, out.data_ptr(), None) != 0
+    assert "leaves" in A._lib.last_error()
+
+
+def test_sliding_window_192x160x128_matches_oracle_and_512_speed(A, orc):
+    """BASELINE configs[3] path (prediction.py:78-109) with the real 128^3 window / stride 64: 192 x 160 x 128 = 2x2x1
+    windows against the oracle loop (fp32 mode, 1e-3), then the 512^3 volume (343 windows) in bf16: finite, in (0, 1),
+    identical for batch 1 and batch 4 (eval mode: InstanceNorm is per sample), and timed."""
+    import time
+    m = build(A, orc, 2, "fp32")
+    o = orc.build_oracle(2, 1, 1, seed=0)
+    x = orc.synthetic_batch(1, (192, 160, 128), 2, seed=19)["image"]
+    got = A.sliding_window_predict(m, x.cuda(), batch=2)
+    ref = orc.sliding_window_predict(o, x)
+    err = float(np.abs(got - ref).max())
+    print(f"192x160x128 assembly vs oracle: max |diff| {err:.2e}")
+    assert got.shape == (192, 160, 128) and err < FP32_ATOL
+    del m
+    mb = build(A, orc, 2, "bf16")
+    g = torch.Generator(device="cuda").manual_seed(23)
+    vol = torch.rand((1, 2, 512, 512, 512), generator=g, device="cuda")
+    A.sliding_window_predict(mb, vol[:, :, :128, :128, :256], batch=1, return_tensor=True)      # warm-up
+    res = {}
+    for batch in (4, 1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res[batch] = A.sliding_window_predict(mb, vol, batch=batch, return_tensor=True)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"512^3 sliding window, 343 windows, batch {batch}: {dt:.3f} s ({512 ** 3 / dt / 1e6:.0f} M output voxels/s)")
+    assert torch.isfinite(res[4]).all() and float(res[4].min()) > 0.0 and float(res[4].max()) < 1.0
+    assert torch.equal(res[1], res[4])

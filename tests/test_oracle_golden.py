@@ -181,3 +181,41 @@ def test_dti_oracle_float32_copies_match_reference_fixture(golden_dir):
         np.testing.assert_array_equal(got64, d[f"out64_{c}"])
         differ += int((got32 != got64).sum())
     assert differ > 100
+
+
+def test_pipeline_oracle_matches_reference_helpers_fixture(golden_dir):
+    """oracle/pipeline_oracle.py against outputs of the reference's own data.py helpers (oracle/make_golden_pipeline.py):
+    the flip / rotate index maps (all 24 combinations), a seeded CropSegData batch including the order of the random
+    draws, the float16 weight exponentiation, and the float64 normalisation of int16 crops -- all bit-exact."""
+    import random
+    import pipeline_oracle as po
+    g = _load(golden_dir, "pipeline_known.npz")
+    n = g["aug_out"].shape[1]
+    code = np.arange(n ** 3, dtype=np.int32).reshape(n, n, n)
+    assert len(g["aug_params"]) == 24
+    for (f0, f1, f2, rot), out in zip(g["aug_params"], g["aug_out"]):
+        c = po.aug_code(None if (f0, f1, f2) == (1, 1, 1) else (f0, f1, f2), {0: None, 1: "left", 2: "right"}[int(rot)])
+        np.testing.assert_array_equal(po.apply_code(code, c), out)
+        x = {0: lambda a: a, 1: po.rotate_left, 2: po.rotate_right}[int(rot)](po.flip(code, (f0, f1, f2)))
+        np.testing.assert_array_equal(x, out)
+    img, label, w16, cube, b = g["img"], g["label"], g["weight16"], int(g["cube"]), int(g["batch"])
+    assert w16.dtype == np.float16 and img.dtype == np.int16
+    for seed in (1, 2):
+        random.seed(100 + seed)
+        np.random.seed(200 + seed)
+        plan = po.draw_stage1_plan(img.shape, b, cube)
+        out = po.crop_batch(img.astype(np.float32), plan["starts"], plan["codes"], cube, label, w16, None, plan["u"], f64_math=False)
+        for k in ("data", "label", "weight"):
+            np.testing.assert_array_equal(out[k], g[f"s1_{seed}_{k}"])
+    out = po.crop_batch(img, [tuple(s) for s in g["s2_starts"]], [0, 0], cube)
+    np.testing.assert_array_equal(out["data"], g["s2_data"])
+    # the host-side plan of the product package draws the same numbers in the same order
+    import seunet_amd as A
+    for seed in (1, 2):
+        random.seed(100 + seed); np.random.seed(200 + seed)
+        a = po.draw_stage1_plan(img.shape, b, cube)
+        random.seed(100 + seed); np.random.seed(200 + seed)
+        assert A.draw_stage1_plan(img.shape, b, cube) == a
+    for f in ((1, 1, -1), (-1, 1, 1), (-1, -1, -1), None):
+        for r in (None, "left", "right"):
+            assert A.aug_code(f, r) == po.aug_code(f, r)
