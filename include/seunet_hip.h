@@ -211,6 +211,30 @@ size_t seunet_dti_workspace_bytes(int h, int w, int z);
 int seunet_dti(const double* pred, int h, int w, int z, double h_thresh, double l_thresh, int pred_dtype, unsigned char* out,
                void* workspace, size_t workspace_bytes, seunet_stream_t s);
 
+/* ---- largest component, hole filling, metric sums -------------------------------------------------------
+ * seunet_largest_component: volume (h, w, z) bytes, non-zero = foreground (the thresholded prediction, prediction.py:110-116).
+ *   rule SEUNET_CC_EVALUATION (train.py:749-757): out = the 26-connected component with the most voxels (ties: the one that
+ *        appears LAST in raster order = cc3d's highest label, `sorted(..)[::-1]`); an empty volume gives an empty mask.
+ *   rule SEUNET_CC_MAXIMUM_3D (util.py:58-75): as above; if that component has no voxel in the slices z//2, z//3, z//3*2 of
+ *        the last axis the second component is taken; then scipy.ndimage.binary_fill_holes (6-connected background that
+ *        does not reach the border becomes foreground).
+ * out: h*w*z bytes of 0/1.  status_dev (device int, optional): 0 ok, 1 no component, 2 no second component (the reference
+ * raises IndexError in both cases under maximum_3d).  Union-find with atomics on labels = minimum linear index: the
+ * result is deterministic.  workspace: seunet_cc_workspace_bytes(h, w, z), caller-owned. */
+#define SEUNET_CC_EVALUATION 0
+#define SEUNET_CC_MAXIMUM_3D 1
+size_t seunet_cc_workspace_bytes(int h, int w, int z);
+int seunet_largest_component(const unsigned char* volume, int h, int w, int z, int rule, unsigned char* out, int* status_dev,
+                             void* workspace, size_t workspace_bytes, seunet_stream_t s);
+/* The integer sums every ATM'22 metric of metrics.py:14-78 is formed from, in one pass over 0/1 byte volumes pred / label /
+ * skeleton and the int32 branch-parsing volume (label, skeleton, parsing optional):
+ * out = u64[8] {sum(pred*label), sum(pred), sum(label), sum(pred*skeleton), sum(skeleton), 0, 0, 0}, then u32[nbins] counts of
+ * skeleton*parsing (np.bincount, metrics.py:16-17), u32[nbins] counts of skeleton*parsing*pred (:19-21), int max id, int
+ * overflow (an id >= nbins was met).  The caller forms the rounded percentages exactly like metrics.py. */
+size_t seunet_metric_out_bytes(int nbins);
+int seunet_metric_sums(const unsigned char* pred, const unsigned char* label, const unsigned char* skeleton, const int* parsing,
+                       long long n, int nbins, void* out, size_t out_bytes, seunet_stream_t s);
+
 /* ---- whole network: SE_UNet.forward (SE_UNet.py:181-238) and its backward ------------------------------- */
 typedef struct seunet_net_desc {
   int batch, in_channel, n_classes;

@@ -16,6 +16,7 @@ F32, BF16 = 0, 1
 CONV_MFMA, CONV_NAIVE = 0, 1
 LOSS_NSUMS = 7
 DTI_F64, DTI_F32 = 0, 1
+CC_EVALUATION, CC_MAXIMUM_3D = 0, 1
 
 
 class Dims(C.Structure):
@@ -72,6 +73,10 @@ PROTOTYPES = {
     "seunet_cat_epilogue_fwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, Dims, _vp]),
     "seunet_cat_epilogue_bwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),
     "seunet_cat_xgrad_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "seunet_cc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "seunet_largest_component": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "seunet_metric_out_bytes": (_sz, [_i]),
+    "seunet_metric_sums": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _sz, _vp]),
     "seunet_crop_batch": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ip, _ip, C.c_double, _i, _vp, _vp, _vp, _vp, _vp]),
     "seunet_hu_two_channel": (_i, [_vp, _i, _ll, _i, _vp, _vp]),
     "seunet_window_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _ip, _vp, _vp]),

@@ -206,6 +206,20 @@ int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_
   return launch_cat_xgrad_reduce(xw_partial, records, c, in_channel, dw, S(s));
 }
 
+size_t seunet_cc_workspace_bytes(int h, int w, int z) {
+  if (h < 1 || w < 1 || z < 1) { fail("cc_workspace_bytes: bad dimensions"); return 0; }
+  return cc_workspace_bytes(h, w, z);
+}
+int seunet_largest_component(const unsigned char* volume, int h, int w, int z, int rule, unsigned char* out, int* status_dev,
+                             void* workspace, size_t workspace_bytes, seunet_stream_t s) {
+  return launch_largest_component(volume, h, w, z, rule, out, status_dev, workspace, workspace_bytes, S(s));
+}
+size_t seunet_metric_out_bytes(int nbins) { return nbins < 1 ? 0 : metric_out_bytes(nbins); }
+int seunet_metric_sums(const unsigned char* pred, const unsigned char* label, const unsigned char* skeleton, const int* parsing,
+                       long long n, int nbins, void* out, size_t out_bytes, seunet_stream_t s) {
+  return launch_metric_sums(pred, label, skeleton, parsing, n, nbins, out, out_bytes, S(s));
+}
+
 int seunet_crop_batch(const void* img, int img_dtype, const unsigned char* label, const void* weight, int weight_dtype,
                       const unsigned char* skeleton, int d, int h, int w, int cube, int ncrop, const int* starts, const int* aug,
                       double weight_exponent, int f64_math, float* data_out, float* label_out, float* weight_out, float* skel_out,

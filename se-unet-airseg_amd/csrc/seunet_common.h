@@ -256,6 +256,13 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, 
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate,
                          Dims din, hipStream_t s);
 int launch_multi_zero(float* const* ptrs, const int* counts, int n, hipStream_t s);
+// connected components / metrics (components.hip)
+size_t cc_workspace_bytes(int H, int W, int Z);
+int launch_largest_component(const unsigned char* vol, int H, int W, int Z, int rule, unsigned char* out, int* status_dev,
+                             void* workspace, size_t ws_bytes, hipStream_t s);
+size_t metric_out_bytes(int nbins);
+int launch_metric_sums(const unsigned char* pred, const unsigned char* label, const unsigned char* skel, const int* parsing, long long n,
+                       int nbins, void* out, size_t out_bytes, hipStream_t s);
 // input pipeline (pipeline.hip)
 int launch_crop_batch(const void* img, int img_dtype, const unsigned char* label, const void* weight, int w_dtype,
                       const unsigned char* skel, int D, int H, int W, int cube, int ncrop, const int* starts, const int* aug,

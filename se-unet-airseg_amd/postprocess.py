@@ -60,6 +60,163 @@ def zero_borders(pred, lo: float = 0.15, hi: float = 0.85):
 
 
 def postprocess_prediction(pred, h_thresh: float = 0.5, l_thresh: float = 0.4):
-    """prediction.py:110-114: double threshold (0.5 / 0.4), then border clearing.  The largest-component filter that
-    follows in the reference (``maximum_3d``, util.py:58-75) is SURVEY 8(f4) and not part of this package."""
+    """prediction.py:110-114: double threshold (0.5 / 0.4), then border clearing.  ``maximum_3d`` (prediction.py:116)
+    is the next step: ``maximum_3d(postprocess_prediction(pred))``."""
     return zero_borders(double_threshold_iteration(pred, h_thresh, l_thresh))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f4): largest 26-connected component (+ hole filling) and the ATM'22 metrics, on the device
+# ----------------------------------------------------------------------------------------------------------------------
+def _as_u8_cuda(a, name):
+    if isinstance(a, np.ndarray):
+        if not torch.cuda.is_available():
+            raise RuntimeError(f"seunet {name}: needs a GPU (no CPU path)")
+        return torch.from_numpy(np.ascontiguousarray(a != 0).view(np.uint8)).cuda(), True
+    if not a.is_cuda:
+        raise RuntimeError(f"seunet {name}: needs a CUDA tensor or a numpy array (no CPU path)")
+    return (a != 0).to(torch.uint8).contiguous(), False
+
+
+def _largest(vol, rule, name):
+    t, as_numpy = _as_u8_cuda(vol, name)
+    if t.dim() != 3:
+        raise ValueError(f"{name} expects a 3-D volume, got shape {tuple(t.shape)}")
+    lib = _lib.load()
+    h, w, z = (int(v) for v in t.shape)
+    with torch.cuda.device(t.device):
+        nbytes = lib.seunet_cc_workspace_bytes(h, w, z)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+        out = torch.empty((h, w, z), dtype=torch.uint8, device=t.device)
+        status = torch.zeros(1, dtype=torch.int32, device=t.device)
+        _lib.check(lib.seunet_largest_component(t.data_ptr(), h, w, z, rule, out.data_ptr(), status.data_ptr(), ws.data_ptr(), nbytes,
+                                                _lib.stream_ptr()), name)
+    return out, int(status.item()), as_numpy
+
+
+def largest_component(pred):
+    """The component rule of ``evaluation_case`` (train.py:749-757, test.py:243-251): the 26-connected component with the
+    most voxels as a uint8 mask (``large_cd``); an empty prediction gives an empty mask (``pred.astype(np.uint8)``).
+    numpy in -> uint8 numpy out; CUDA tensor in -> uint8 CUDA tensor out."""
+    out, _, as_numpy = _largest(pred, _lib.CC_EVALUATION, "largest_component")
+    return out.cpu().numpy() if as_numpy else out
+
+
+def maximum_3d(region01):
+    """util.py:58-75 (called at prediction.py:116): largest 26-connected component, replaced by the second largest when it
+    misses the three test slices of the last axis, then ``binary_fill_holes``.  Returns a bool array (numpy in) like the
+    reference, or a uint8 CUDA tensor (tensor in).  Raises IndexError where the reference does (no component / no second
+    component)."""
+    out, status, as_numpy = _largest(region01, _lib.CC_MAXIMUM_3D, "maximum_3d")
+    if status != 0:
+        raise IndexError("list index out of range (maximum_3d: %s, util.py:%d)" %
+                         (("the volume has no foreground component", 65) if status == 1 else ("no second component to fall back to", 71)))
+    return out.cpu().numpy().astype(bool) if as_numpy else out
+
+
+class MetricSums:
+    """The integer sums metrics.py:14-78 is built from, computed in one pass on the device (``seunet_metric_sums``)."""
+
+    def __init__(self, pred, label=None, skeleton=None, parsing=None, nbins: int = 4096):
+        p, _ = _as_u8_cuda(pred, "metrics")
+        lab = _as_u8_cuda(label, "metrics")[0] if label is not None else None
+        sk = _as_u8_cuda(skeleton, "metrics")[0] if skeleton is not None else None
+        pa = None
+        if parsing is not None:
+            pa = (torch.from_numpy(np.ascontiguousarray(parsing)).cuda() if isinstance(parsing, np.ndarray) else parsing)
+            pa = pa.to(device=p.device, dtype=torch.int32).contiguous()
+        for t in (lab, sk, pa):
+            if t is not None and t.numel() != p.numel():
+                raise ValueError("metrics: all volumes must have the prediction's size")
+        lib = _lib.load()
+        with torch.cuda.device(p.device):
+            nb = lib.seunet_metric_out_bytes(nbins)
+            out = torch.empty(nb, dtype=torch.uint8, device=p.device)
+            _lib.check(lib.seunet_metric_sums(p.data_ptr(), _lib.ptr(lab), _lib.ptr(sk), _lib.ptr(pa), p.numel(), nbins, out.data_ptr(), nb,
+                                              _lib.stream_ptr()), "metric_sums")
+        raw = out.cpu().numpy()
+        sums = raw[:64].view(np.uint64)
+        self.n = p.numel()
+        self.inter, self.pred, self.label, self.pred_skel, self.skel = (np.uint64(v) for v in sums[:5])
+        self.branch_label = raw[64:64 + 4 * nbins].view(np.uint32).astype(np.int64)
+        self.branch_pred = raw[64 + 4 * nbins:64 + 8 * nbins].view(np.uint32).astype(np.int64)
+        extra = raw[64 + 8 * nbins:64 + 8 * nbins + 8].view(np.int32)
+        self.max_id = int(extra[0])
+        if int(extra[1]):
+            raise ValueError(f"metrics: a branch id >= nbins ({nbins}) was met; pass a larger nbins")
+
+
+def branch_detected_calculation(pred, label_parsing, label_skeleton, thresh=0.8, sums: "MetricSums" = None):
+    """metrics.py:14-29 -> (total_branch_num, detected_branch_num, detected_branch_ratio)."""
+    s = sums or MetricSums(pred, None, label_skeleton, label_parsing)
+    label_branch_bincount = s.branch_label[1:s.max_id + 1]
+    total_branch_num = label_branch_bincount.shape[0]
+    nz = np.nonzero(s.branch_pred[1:])[0]
+    pred_branch_bincount = s.branch_pred[1:(int(nz[-1]) + 2 if nz.size else 1)]          # np.bincount stops at the largest id present
+    if total_branch_num != pred_branch_bincount.shape[0]:
+        lack_num = total_branch_num - pred_branch_bincount.shape[0]
+        pred_branch_bincount = np.concatenate((pred_branch_bincount, np.zeros(lack_num)))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        branch_ratio_array = pred_branch_bincount / label_branch_bincount
+    branch_ratio_array = np.where(branch_ratio_array >= thresh, 1, 0)
+    detected_branch_num = np.count_nonzero(branch_ratio_array)
+    detected_branch_ratio = round((detected_branch_num * 100) / total_branch_num, 2)
+    return total_branch_num, detected_branch_num, detected_branch_ratio
+
+
+def dice_coefficient_score_calculation(pred, label, smooth=1e-5, sums: "MetricSums" = None):
+    """metrics.py:32-37."""
+    s = sums or MetricSums(pred, label)
+    return round(((2.0 * s.inter + smooth) / (s.pred + s.label + smooth)) * 100, 2)
+
+
+def tree_length_calculation(pred, label_skeleton, smooth=1e-5, sums: "MetricSums" = None):
+    """metrics.py:40-44."""
+    s = sums or MetricSums(pred, None, label_skeleton)
+    return round((s.pred_skel + smooth) / (s.skel + smooth) * 100, 2)
+
+
+def false_positive_rate_calculation(pred, label, smooth=1e-5, sums: "MetricSums" = None):
+    """metrics.py:47-52."""
+    s = sums or MetricSums(pred, label)
+    fp = np.uint64(s.pred - s.inter) + smooth
+    return round(fp * 100 / (np.float64(s.n - int(s.label)) + smooth), 3)
+
+
+def false_negative_rate_calculation(pred, label, smooth=1e-5, sums: "MetricSums" = None):
+    """metrics.py:55-60."""
+    s = sums or MetricSums(pred, label)
+    fn = np.uint64(s.label - s.inter) + smooth
+    return round(fn * 100 / (s.label + smooth), 3)
+
+
+def sensitivity_calculation(pred, label, sums: "MetricSums" = None):
+    """metrics.py:63-65."""
+    return round(100 - false_negative_rate_calculation(pred, label, sums=sums), 3)
+
+
+def specificity_calculation(pred, label, sums: "MetricSums" = None):
+    """metrics.py:68-70."""
+    return round(100 - false_positive_rate_calculation(pred, label, sums=sums), 3)
+
+
+def precision_calculation(pred, label, smooth=1e-5, sums: "MetricSums" = None):
+    """metrics.py:73-78."""
+    s = sums or MetricSums(pred, label)
+    tp = s.inter + smooth
+    return round(tp * 100 / (s.pred + smooth), 3)
+
+
+def evaluation_case(pred, label, skeleton, parsing, nbins: int = 4096):
+    """The arithmetic of ``evaluation_case`` (train.py:740-775, minus its file reads): largest 26-connected component of
+    ``pred``, then (TD, BD, DSC, Pre, Sen, Spe) against the mask, the skeleton (``skeleton > 0``) and the branch parsing.
+    One labelling pass + one reduction pass on the device; the percentages are rounded on the host like metrics.py."""
+    large_cd = largest_component(pred if not isinstance(pred, np.ndarray) else torch.from_numpy(np.ascontiguousarray(pred != 0)).cuda())
+    s = MetricSums(large_cd, label, skeleton, parsing, nbins)
+    _, _, bd = branch_detected_calculation(None, None, None, sums=s)
+    dsc = dice_coefficient_score_calculation(None, None, sums=s)
+    td = tree_length_calculation(None, None, sums=s)
+    sen = sensitivity_calculation(None, None, sums=s)
+    spe = specificity_calculation(None, None, sums=s)
+    pre = precision_calculation(None, None, sums=s)
+    return td, bd, dsc, pre, sen, spe

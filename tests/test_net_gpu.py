@@ -535,7 +535,7 @@ def _dp_worker(rank, world, port, backend, q):
         grads = [p.grad for p in m.parameters() if p.grad is not None]
         zero_copy = _ddp._flat_view(grads) is not None            # real backward -> one contiguous bucket
         n = _ddp.allreduce_gradients(m.parameters())
-        out = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+        out = {k: p.grad.cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}   # by value (the worker exits)
         q.put((rank, float(loss.detach()), bool(zero_copy), int(n), out if rank == 0 else None))
         _dist.barrier()
         _dist.destroy_process_group()
@@ -568,7 +568,7 @@ def _run_dp_equivalence(A, orc, backend):
     for k, p in m.named_parameters():
         if p.grad is None:
             continue
-        ref, got = p.grad.cpu().double(), res[0][4][k].double()
+        ref, got = p.grad.cpu().double(), torch.from_numpy(res[0][4][k]).double()
         if k.endswith("conv1.bias"):
             assert float(got.abs().max()) <= 1e-6
             continue

@@ -219,3 +219,49 @@ def test_pipeline_oracle_matches_reference_helpers_fixture(golden_dir):
     for f in ((1, 1, -1), (-1, 1, 1), (-1, -1, -1), None):
         for r in (None, "left", "right"):
             assert A.aug_code(f, r) == po.aug_code(f, r)
+
+
+def test_metrics_oracle_matches_reference_metrics_module_fixture(golden_dir):
+    """oracle/components_oracle.py's metric functions against values produced by the reference's own metrics.py
+    (oracle/make_golden_components.py): identical rounded percentages and branch counts."""
+    import components_oracle as co
+    g = _load(golden_dir, "metrics_known.npz")
+    for c in range(int(g["n"])):
+        pred, label, skel, parsing = g[f"pred_{c}"], g[f"label_{c}"], g[f"skel_{c}"], g[f"parsing_{c}"].astype(np.int32)
+        tot, det, bd = co.branch_detected_calculation(pred, parsing, skel)
+        vals = [bd, co.dice_coefficient_score_calculation(pred, label), co.tree_length_calculation(pred, skel),
+                co.false_positive_rate_calculation(pred, label), co.false_negative_rate_calculation(pred, label),
+                co.sensitivity_calculation(pred, label), co.specificity_calculation(pred, label), co.precision_calculation(pred, label)]
+        assert [tot, det] == list(g[f"branches_{c}"])
+        assert vals == list(g[f"values_{c}"]), (c, vals, list(g[f"values_{c}"]))
+
+
+def test_component_oracle_known_answers():
+    """maximum_3d (util.py:58-75) / evaluation_case's component rule on cases whose answers follow from the definitions."""
+    import components_oracle as co
+    v = np.zeros((12, 12, 12), dtype=np.uint8)
+    v[1:4, 1:4, 1:4] = 1                       # 27 voxels, reaches no test slice (z = 6, 4, 8)
+    v[6:9, 6:9, 3:9] = 1                       # 54 voxels, reaches them
+    v[4, 4, 4] = 1                             # 26-connected bridge? (3,3,3)-(4,4,4)-(5,5,5): corner contacts only
+    v[5, 5, 4] = 1                             # (4,4,4)-(5,5,4) face-diagonal contact; (5,5,4)-(6,6,3): corner contact
+    big = co.largest_component(v)
+    assert big.sum() == 27 + 54 + 2            # everything hangs together through corner / edge contacts (26-connectivity)
+    v2 = np.zeros((12, 12, 12), dtype=np.uint8)
+    v2[0:5, 0:5, 0:3] = 1                      # 75 voxels, z in 0..2: misses z = 6, 4, 8
+    v2[7:10, 7:10, 3:9] = 1                    # 54 voxels
+    assert co.largest_component(v2).sum() == 75
+    m = co.maximum_3d(v2)
+    assert m.dtype == bool and m.sum() == 54 and m[8, 8, 5]          # the second largest is taken
+    shell = np.zeros((9, 9, 9), dtype=np.uint8)
+    shell[1:8, 1:8, 1:8] = 1
+    shell[3:6, 3:6, 3:6] = 0                   # enclosed cavity of 27 voxels
+    assert co.largest_component(shell).sum() == 343 - 27 and co.maximum_3d(shell).sum() == 343
+    shell[4, 4, 0:4] = 0                       # a 6-connected channel to the border: no longer a hole
+    assert co.maximum_3d(shell).sum() == 343 - 27 - 2
+    tie = np.zeros((6, 6, 12), dtype=np.uint8)
+    tie[0, 0, 0:3] = 1
+    tie[5, 5, 5:8] = 1                         # equal sizes: the reference takes the HIGHER label = later in raster order
+    assert co.largest_component(tie)[5, 5, 6] == 1 and co.largest_component(tie)[0, 0, 1] == 0
+    with pytest.raises(IndexError):
+        co.maximum_3d(np.zeros((4, 4, 4), dtype=np.uint8))
+    assert co.largest_component(np.zeros((4, 4, 4), dtype=np.uint8)).sum() == 0

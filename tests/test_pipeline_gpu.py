@@ -57,7 +57,7 @@ def test_reference_fixture_stage1_batches_bit_exact(A, golden_dir):
 @pytest.mark.parametrize("code", list(range(16)))
 def test_every_axis_map_against_oracle(A, po, code):
     img, label, w16, skel = _case(code, (70, 66, 100))
-    starts = [(3, 1, 36), (38, 2, 0)]
+    starts = [(3, 1, 36), (6, 2, 0)]
     t = lambda a: torch.from_numpy(a).cuda()
     got = A.crop_batch(t(img), starts, 64, t(label), t(w16), t(skel), [code, 15 - code], u=0.37)
     want = po.crop_batch(img, starts, [code, 15 - code], 64, label, w16, skel, 0.37)
@@ -76,8 +76,8 @@ def test_weight_power_in_wider_dtypes(A, po, wdtype):
     t = lambda a: torch.from_numpy(a).cuda()
     got = A.crop_batch(t(img), [(4, 4, 4)], 32, t(label), t(w), None, None, u=0.811)["weight"].cpu().numpy()
     want = po.crop_batch(img, [(4, 4, 4)], [0], 32, label, w, None, 0.811)["weight"]
-    ulp = np.spacing(np.abs(want).astype(np.float32))
-    assert np.all(np.abs(got - want) <= ulp), float(np.abs(got - want).max())
+    ulp = np.spacing(np.abs(want).astype(np.float32))       # numpy's float32 power is its own SIMD powf (not correctly rounded):
+    assert np.all(np.abs(got - want) <= ulp), float(np.abs(got - want).max())     # measured 4 % of the voxels off by one ulp
     print("f32-rounded mismatches:", int((got != want).sum()), "of", got.size)
 
 
