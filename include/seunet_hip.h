@@ -51,6 +51,18 @@ int seunet_conv_stats_slots(int impl, int taps, int dilation, seunet_dims dims);
 int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
                       int cin, const void* weights, int transpose_flip, const float* bias, int ndst, void* const* dst,
                       const int* dst_c, const int* dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s);
+/* Streaming variant of the 3x3x3 convolution for the small-channel full-resolution layers (ec1 / ec2 / ec3 / dc6 forward and
+ * data gradient; SE_UNet.py:108-110,147): one source tensor of 8 / 16 / 32 channels, one destination of <= 32 (16 when the
+ * source has 32) channels, bf16, dilation 1 | 2.  A workgroup marches along z with the input planes arriving by LDS-DMA
+ * (csrc/conv_stream.hip).  Weights: seunet_conv3d_stream_pack (transpose_flip = 1: data-gradient operator).  stats_partial:
+ * [n][seunet_conv3d_stream_slots][dst_c][2] f64 (optional), same meaning as for seunet_conv3d_fwd. */
+int seunet_conv3d_stream_supported(int dtype, int dilation, int src_c, int dst_c);
+size_t seunet_conv3d_stream_wpack_bytes(int src_c);
+int seunet_conv3d_stream_slots(int dilation, seunet_dims dims);
+int seunet_conv3d_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int transpose_flip, int src_c, int dst_c, void* wpack,
+                              seunet_stream_t s);
+int seunet_conv3d_stream(int dtype, int dilation, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
+                         int dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s);
 size_t seunet_conv3d_wgrad_workspace_bytes(int taps, int cin, int cout);
 int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
                         int cin, const void* dy, int cout, float* dw, void* workspace, size_t workspace_bytes,

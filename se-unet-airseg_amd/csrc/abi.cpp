@@ -62,6 +62,17 @@ int seunet_conv3d_fwd(int dtype, int impl, int taps, int dilation, int nsrc, con
   }
   return launch_conv_igemm(dtype, taps, dilation, sl, cin, weights, bias, dl, stats_partial, D(dims), S(s));
 }
+int seunet_conv3d_stream_supported(int dtype, int dilation, int src_c, int dst_c) { return conv_stream_supported(dtype, 27, dilation, src_c, dst_c) ? 1 : 0; }
+size_t seunet_conv3d_stream_wpack_bytes(int src_c) { return conv_stream_wpack_bytes(src_c); }
+int seunet_conv3d_stream_slots(int dilation, seunet_dims dims) { return conv_stream_slots(D(dims), dilation); }
+int seunet_conv3d_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int transpose_flip, int src_c, int dst_c, void* wpack,
+                              seunet_stream_t s) {
+  return launch_conv_stream_pack(dtype, w, cin_w, cout_w, transpose_flip, src_c, dst_c, wpack, S(s));
+}
+int seunet_conv3d_stream(int dtype, int dilation, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
+                         int dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s) {
+  return launch_conv_stream(dtype, dilation, src, src_c, wpack, bias, dst, dst_c, dst_accumulate, stats_partial, D(dims), S(s));
+}
 size_t seunet_conv3d_wgrad_workspace_bytes(int taps, int cin, int cout) { return wgrad_workspace_bytes(taps, cin, cout); }
 int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c, int cin,
                         const void* dy, int cout, float* dw, void* workspace, size_t workspace_bytes, seunet_dims dims,

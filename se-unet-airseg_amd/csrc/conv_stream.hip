@@ -1,0 +1,432 @@
+// Streaming 3x3x3 convolution for the small-channel full-resolution layers (reference nn.Conv3d at SE_UNet.py:15 for
+// ec1 / ec2 / ec3 / dc6, forward and data gradient): 8..32 input channels, <= 32 output channels, dilation 1 or 2.
+//
+// Why a second conv kernel: on these layers the tiled implicit-GEMM kernel (conv_igemm.hip) spends ~8x its MFMA time per
+// tile on fixed work (index plan, first fetch at full HBM latency, statistics tree, stores) with two workgroups per CU to
+// hide it -- 0.29..0.69 ms per launch against HBM floors of 0.05..0.15 ms (profiles/r01_g_*).  Here a workgroup owns an
+// 8 x 32 (y, x) patch and MARCHES along z:
+//   * input-stationary in z: step s stages ONE input plane and adds its contribution to the three output planes s-1, s,
+//     s+1 (accumulators of three planes live in registers, roles rotate with a 3x unrolled loop), so every LDS fragment
+//     read feeds 3 (dz) x 1-2 (dy) MFMAs instead of one, and the finished plane s-1 is stored while the march goes on;
+//   * the planes arrive by LDS-DMA (global_load_lds_dwordx4, inline asm so that hipcc neither counts nor drains them) into a
+//     4-slot ring two steps ahead of their use: counted s_waitcnt vmcnt(N) + one raw s_barrier per step, the HBM latency
+//     of a plane is hidden behind two steps of MFMAs; padding voxels read a zero page;
+//   * weights live in registers for the whole march (27 taps x 16 B per lane), no weight LDS, no K-chunk loop;
+//   * InstanceNorm partial sums are carried per lane across the march (shifted by the lane's first value, f32) and reduced
+//     once per workgroup (f64), not once per 512-voxel tile.
+// MFMA shapes by channel counts (weights = A operand, so a lane owns one voxel and runs of 4 consecutive channels):
+//   CIN 16 -> COUT <= 32 : v_mfma_f32_32x32x16 (K = the 16 channels of one tap)                       ec3 fwd, dc6 dgrad, ec2 dgrad
+//   CIN 32 -> COUT <= 16 : v_mfma_f32_16x16x32 (K = the 32 channels of one tap)                       dc6 fwd, ec3 dgrad
+//   CIN  8 -> COUT <= 16 : v_mfma_f32_16x16x32 with the three x-taps folded into K (3 x 8 channels of the contiguous
+//                          voxels x-1, x, x+1 + 8 zero weights): 9 MFMAs per 16 voxels instead of 27   ec1 fwd, ec2 fwd
+// Dilation 2 marches each z-parity class separately (planes z, z+2, ...) and keeps the natural layout in the plane (halo 2).
+// LDS image of a plane: planar [16-B piece of the channels][voxel of the halo patch][16 B]; fragment reads are ds_read_b128
+// of consecutive voxels (conflict-free), DMA instructions write 1 KB contiguous.
+#include "seunet_common.h"
+#include <utility>
+
+namespace seunet {
+
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+
+struct StreamArgs {
+  const void* src; const void* wpack; const float* bias;
+  void* dst; int dstC; int dacc; int cout;
+  double* stats; const void* zero;
+  int N, D, H, W;
+  int nyb, nxb, nzseg, zsteps;      // patches, z segments (per parity class), output planes per segment
+};
+
+static constexpr int ST_TY = 8, ST_TX = 32, ST_RING = 4;
+
+template <int CIN, int COUTP, bool XFOLD, int DIL> struct StreamGeo {
+  static constexpr int NP = CIN / 8;
+  static constexpr int HX = ST_TX + 2 * DIL + (XFOLD ? 1 : 0), HY = ST_TY + 2 * DIL;
+  static constexpr int NVP = HX * HY, G = (NVP + 63) / 64;
+  static constexpr int PS = G * 1024, PLANE = NP * PS;
+  static constexpr int ITEMS = (NP * G + 3) / 4;                 // DMA wave-instructions per wave and plane
+  static constexpr int NB = COUTP == 32 ? 32 : 16, NBX = ST_TX / NB;
+  static constexpr int NDX = XFOLD ? 1 : 3, NTAP = 9 * NDX;
+  static constexpr int STORES = COUTP == 32 ? 2 * 4 : 2 * NBX;   // store wave-instructions per wave and step
+  static constexpr int LDS = ST_RING * PLANE + 1024;            // + a 1-KB dump for the padding DMA instructions
+};
+
+__device__ __forceinline__ void stream_dma16(const void* gsrc, unsigned lds_dst) {
+  // one LDS-DMA wave-instruction: 64 lanes x 16 B, LDS destination = lds_dst + 16 * lane (M0 carries the base)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void stream_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <typename T, int CIN, int COUTP, bool XFOLD, int DIL>
+__global__ void __launch_bounds__(256, 1)
+conv_stream_kernel(StreamArgs a) {
+  using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL>;
+  constexpr int NP = Geo::NP, HX = Geo::HX, HY = Geo::HY, NVP = Geo::NVP, G = Geo::G, PS = Geo::PS, PLANE = Geo::PLANE;
+  constexpr int ITEMS = Geo::ITEMS, NB = Geo::NB, NBX = Geo::NBX, NDX = Geo::NDX, NTAP = Geo::NTAP, STORES = Geo::STORES;
+  constexpr int ACCR = COUTP == 32 ? 16 : 4;
+  typedef typename std::conditional<COUTP == 32, f32x16, f32x4>::type AccT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // patch / segment of this workgroup (XCD-contiguous order of the patches)
+  int t;
+  {
+    const int nt = gridDim.x, b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int xb = t % a.nxb, yb = t / a.nxb;
+  const int seg = blockIdx.y / DIL, pz = blockIdx.y % DIL;       // z = pz + DIL * (plane index in the parity class)
+  const int n = blockIdx.z;
+  const int x0 = xb * ST_TX, y0 = yb * ST_TY;
+  const int q0 = seg * a.zsteps;                                   // first output plane (parity units)
+  const int nplanes = (a.D - pz + DIL - 1) / DIL;                  // planes of this parity class
+  const int q1 = min(q0 + a.zsteps, nplanes);
+  const int nsteps = q1 - q0 + 2;                                  // input planes q0-1 .. q1
+  const long long plane_bytes = (long long)a.H * a.W * CIN * (long long)sizeof(T);
+  const unsigned char* src_n = reinterpret_cast<const unsigned char*>(a.src) + (long long)n * a.D * plane_bytes;
+
+  // ---- DMA plan: item it of this wave = (piece, 64-voxel group) number wave + 4 * it ----
+  unsigned doff[ITEMS];            // byte offset inside a z-plane of this lane's 16 bytes; 0xFFFFFFFF = padding (zero page)
+  unsigned dlds[ITEMS];            // LDS byte offset inside a plane image (wave-uniform)
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int id = wave + 4 * it;
+    const int p = id / G, gi = id % G;
+    const int v = gi * 64 + lane;
+    const int hy = v / HX, hx = v % HX;
+    const int y = y0 - DIL + hy, x = x0 - DIL + hx;
+    const bool ok = id < NP * G && v < NVP && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    doff[it] = ok ? (unsigned)(((y * a.W + x) * CIN + p * 8) * (int)sizeof(T)) : 0xFFFFFFFFu;
+    dlds[it] = (unsigned)(p * PS + gi * 1024);
+  }
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
+  auto dma_item = [&](int s, auto it_c) __attribute__((always_inline)) {   // plane of step s -> ring slot s % 4
+    constexpr int it = decltype(it_c)::value;
+    if constexpr (it < ITEMS) {
+      // every wave issues exactly ITEMS instructions per plane (the vmcnt arithmetic of the march counts on it): an item
+      // number beyond the plane's NP * G pieces copies the zero page into the dump area
+      const bool real = wave + 4 * it < NP * G;                     // wave-uniform
+      const int pl = q0 - 1 + s;                                    // plane index in the parity class
+      const int z = pz + DIL * pl;
+      const bool zok = real && pl >= 0 && z < a.D && s < nsteps;    // wave-uniform
+      const unsigned char* base = src_n + (long long)(zok ? z : 0) * plane_bytes;
+      const unsigned char* gp = (zok && doff[it] != 0xFFFFFFFFu) ? base + doff[it] : zero_page;
+      stream_dma16(gp, real ? lds_base + (unsigned)((s & 3) * PLANE) + dlds[it] : lds_base + (unsigned)(ST_RING * PLANE));
+    }
+  };
+  auto dma_plane = [&](int s) __attribute__((always_inline)) {
+    [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+      (dma_item(s, std::integral_constant<int, I>{}), ...);
+    }(std::make_integer_sequence<int, ITEMS>{});
+  };
+
+  // ---- weights: registers for the whole march.  wpack: [tap][lane][8 elements] ----
+  bf16x8 wreg[NTAP];
+  {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.wpack) + lane;
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) wreg[k] = __builtin_bit_cast(bf16x8, wp[k * 64]);
+  }
+  // ---- fragment geometry ----
+  // 16x16x32 (COUTP 16): lane = (voxel n = lane & 15, k-group g = lane >> 4): piece g of the voxel (XFOLD: the only piece of voxel + g)
+  // 32x32x16 (COUTP 32): lane = (voxel n = lane & 31, k-half h = lane >> 5): piece h of the voxel
+  const int fn = COUTP == 32 ? (lane & 31) : (lane & 15);
+  const int fg = COUTP == 32 ? (lane >> 5) : (lane >> 4);
+  // output rows of this wave: ra and ra + DIL (dilation 2: the two rows of one y-parity class share their input rows)
+  const int ra = DIL == 1 ? 2 * wave : (wave >> 1) * 4 + (wave & 1);
+  // LDS byte offset of the lane's fragment for input row index ri = 0..3 (y = ra + DIL * (ri - 1)), x-block xbk, tap dx:
+  //   ((ra + DIL*ri) * HX + xbk*NB + fn + DIL*(dx+1)) * 16 + piece * PS      (halo origin = -DIL in y and x)
+  const int frag0 = XFOLD ? ((ra * HX + fn + fg) * 16) : ((ra * HX + fn) * 16 + fg * PS);
+
+  AccT acc[3][2][NBX];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int b = 0; b < NBX; ++b)
+#pragma unroll
+        for (int e = 0; e < ACCR; ++e) acc[i][r][b][e] = 0.f;
+
+  // channel of accumulator register e of this lane
+  auto chan = [&](int e) __attribute__((always_inline)) -> int {
+    if constexpr (COUTP == 32) return (e & 3) + 8 * (e >> 2) + 4 * fg;
+    else return 4 * fg + e;
+  };
+  float bias_r[ACCR];
+#pragma unroll
+  for (int e = 0; e < ACCR; ++e) { const int c = chan(e); bias_r[e] = (a.bias != nullptr && c < a.cout) ? a.bias[c] : 0.f; }
+  // running InstanceNorm sums of this lane: deviations from the lane's first value of each channel (f32)
+  float sh[ACCR], s1[ACCR], s2[ACCR];
+  float cnt = 0.f;
+  bool have_shift = false;
+#pragma unroll
+  for (int e = 0; e < ACCR; ++e) { sh[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+
+  // destination: buffer descriptor over this sample (range-checked 32-bit offsets; padding voxels use an offset beyond it)
+  const long long dst_sample = (long long)a.D * a.H * a.W * a.dstC * (long long)sizeof(T);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<unsigned char*>(a.dst) + (long long)n * dst_sample, 0, (int)dst_sample, 0x00020000);
+
+  // ---- one step: input plane of step S (ring slot S & 3) -> accumulators; PH = S % 3 ----
+  auto compute = [&](int s, auto ph_c) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    const unsigned char* pl = smem + (s & 3) * PLANE;
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+#pragma unroll
+      for (int dxi = 0; dxi < NDX; ++dxi) {
+        bf16x8 fr[NBX];
+#pragma unroll
+        for (int b = 0; b < NBX; ++b) {
+          const int off = frag0 + ((DIL * ri) * HX + b * NB + (XFOLD ? 0 : DIL * dxi)) * 16;
+          fr[b] = *reinterpret_cast<const bf16x8*>(pl + off);
+        }
+#pragma unroll
+        for (int ro = 0; ro < 2; ++ro) {                 // output row ra + DIL*ro uses input row ri with dy = ri - 1 - ro
+          const int dy = ri - 1 - ro;
+          if (dy < -1 || dy > 1) continue;
+#pragma unroll
+          for (int dz = -1; dz <= 1; ++dz) {             // output plane s - dz
+            const int ai = (PH - dz + 3) % 3;
+            const int tap = ((dz + 1) * 3 + (dy + 1)) * NDX + dxi;
+#pragma unroll
+            for (int b = 0; b < NBX; ++b) {
+              if constexpr (COUTP == 32)
+                acc[ai][ro][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap], fr[b], acc[ai][ro][b], 0, 0, 0);
+              else
+                acc[ai][ro][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap], fr[b], acc[ai][ro][b], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // the prefetch of the plane two steps ahead, spread over the MFMA block: items ri, ri + 4 after input row ri
+      [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+        (((I % 4) == ri ? dma_item(s + 2, std::integral_constant<int, I>{}) : (void)0), ...);
+      }(std::make_integer_sequence<int, ITEMS>{});
+    }
+  };
+
+  // ---- epilogue of the finished output plane q = (q0 - 1 + s) - 1 held in acc[(PH + 2) % 3] ----
+  auto finish = [&](int s, auto ph_c) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    constexpr int ai = (PH + 2) % 3;
+    const int q = q0 + s - 2;                                       // parity-class plane index
+    const int z = pz + DIL * q;
+    const bool zok = q >= q0 && q < q1;                             // wave-uniform
+#pragma unroll
+    for (int ro = 0; ro < 2; ++ro) {
+      const int y = y0 + ra + DIL * ro;
+#pragma unroll
+      for (int b = 0; b < NBX; ++b) {
+        const int x = x0 + b * NB + fn;
+        const bool ok = zok && y < a.H && x < a.W;
+        float v[ACCR];
+#pragma unroll
+        for (int e = 0; e < ACCR; ++e) v[e] = acc[ai][ro][b][e] + bias_r[e];
+        if (a.stats != nullptr) {
+          if (ok && !have_shift) {
+#pragma unroll
+            for (int e = 0; e < ACCR; ++e) sh[e] = v[e];
+          }
+          have_shift = have_shift || ok;
+          if (ok) {
+            cnt += 1.f;
+#pragma unroll
+            for (int e = 0; e < ACCR; ++e) { const float d = v[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+          }
+        }
+        const unsigned vox = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
+        // runs of 4 consecutive channels -> 8-byte pieces
+#pragma unroll
+        for (int pc = 0; pc < ACCR / 4; ++pc) {
+          const int c0 = chan(4 * pc);
+          const bool cok = ok && c0 < a.cout;
+          const unsigned off = cok ? (vox * (unsigned)a.dstC + (unsigned)c0) * (unsigned)sizeof(T) : 0x80000000u;   // beyond the sample: dropped
+          float w4[4] = {v[4 * pc], v[4 * pc + 1], v[4 * pc + 2], v[4 * pc + 3]};
+          if (a.dacc) {
+            const u32x2s o = __builtin_amdgcn_raw_buffer_load_b64(rd, off, 0, 0);
+            w4[0] += bf16_bits_to_f32(o.x & 0xffffu); w4[1] += bf16_bits_to_f32(o.x >> 16);
+            w4[2] += bf16_bits_to_f32(o.y & 0xffffu); w4[3] += bf16_bits_to_f32(o.y >> 16);
+          }
+          u32x2s u;
+          u.x = f32_to_bf16_bits(w4[0]) | (f32_to_bf16_bits(w4[1]) << 16);
+          u.y = f32_to_bf16_bits(w4[2]) | (f32_to_bf16_bits(w4[3]) << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(u, rd, off, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < ACCR; ++e) acc[ai][ro][b][e] = 0.f;
+      }
+    }
+  };
+
+  // ---- the march ----
+  constexpr int LW = ITEMS;      // DMA instructions per wave and plane (waves with fewer real items are padded below)
+  dma_plane(0);
+  dma_plane(1);
+  stream_wait_vm<LW>();          // plane 0 has landed (this wave's part); plane 1 may be in flight
+  __builtin_amdgcn_s_barrier();
+  for (int s0 = 0; s0 < nsteps; s0 += 3) {
+    [&]<int... PH>(std::integer_sequence<int, PH...>) __attribute__((always_inline)) {
+      ([&]() __attribute__((always_inline)) {
+        const int s = s0 + PH;
+        if (s < nsteps) {
+          if (s > 0) {
+            stream_wait_vm<LW + STORES>();   // only the prefetch and the stores issued during the previous step may be in flight: plane s has landed
+            __builtin_amdgcn_s_barrier();
+          }
+          compute(s, std::integral_constant<int, PH>{});
+          finish(s, std::integral_constant<int, PH>{});
+        }
+      }(), ...);
+    }(std::make_integer_sequence<int, 3>{});
+  }
+
+  // ---- InstanceNorm partial sums of this workgroup: un-shift in f64, reduce over the lanes that hold the same channels,
+  //      then over the four waves (fixed order), one record per workgroup ----
+  if (a.stats != nullptr) {
+    stream_wait_vm<0>();
+    __syncthreads();             // the ring is dead: reuse its first bytes
+    double* red = reinterpret_cast<double*>(smem);     // [4 waves][COUTP][2]
+    const double dc = (double)cnt;
+#pragma unroll
+    for (int e = 0; e < ACCR; ++e) {
+      const double d0 = (double)sh[e];
+      double t1 = (double)s1[e] + dc * d0;
+      double t2 = (double)s2[e] + 2.0 * d0 * (double)s1[e] + dc * d0 * d0;
+      constexpr int GROUP = COUTP == 32 ? 32 : 16;
+#pragma unroll
+      for (int off = 1; off < GROUP; off <<= 1) { t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
+      if (fn == 0) {
+        const int c = chan(e);
+        red[(wave * COUTP + c) * 2] = t1;
+        red[(wave * COUTP + c) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < COUTP * 2) {
+      const int c = tid >> 1, k = tid & 1;
+      if (c < a.cout) {
+        const double tot = ((red[(0 * COUTP + c) * 2 + k] + red[(1 * COUTP + c) * 2 + k]) + red[(2 * COUTP + c) * 2 + k]) +
+                           red[(3 * COUTP + c) * 2 + k];
+        const long long slot = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long long slots = (long long)gridDim.y * gridDim.x;
+        a.stats[(((long long)n * slots + slot) * a.cout + c) * 2 + k] = tot;
+      }
+    }
+  } else {
+    stream_wait_vm<0>();         // no DMA may outlive the workgroup's LDS allocation
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight packing: PyTorch (Cout, Cin, 3, 3, 3) f32 -> [tap][lane][8] MFMA A-operand fragments
+// ------------------------------------------------------------------------------------------------------------------
+struct StreamPackArgs { const float* w; void* out; int cin_w, cout_w, tflip, cin_e, cout_e, coutp, xfold; };
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+conv_stream_pack_kernel(StreamPackArgs p) {
+  // blockIdx.x = packed tap index; one wave writes the 64 fragments of that tap
+  const int lane = threadIdx.x;
+  const int ndx = p.xfold ? 1 : 3;
+  const int k = blockIdx.x;                   // ((dz*3 + dy) * ndx + dxi)
+  const int dxi = k % ndx, zy = k / ndx;
+  const int row = p.coutp == 32 ? (lane & 31) : (lane & 15);     // output channel
+  const int grp = p.coutp == 32 ? (lane >> 5) : (lane >> 4);     // k-group: 8 elements
+  T* out = reinterpret_cast<T*>(p.out) + ((size_t)k * 64 + lane) * 8;
+  for (int j = 0; j < 8; ++j) {
+    int ci, dx;
+    if (p.xfold) { ci = j; dx = grp; }        // K = (x-tap grp, channel j); grp 3 = zero padding
+    else { ci = 8 * grp + j; dx = dxi; }
+    float v = 0.f;
+    if (row < p.cout_e && ci < p.cin_e && dx < 3) {
+      const int tap = zy * 3 + dx;
+      // effective operator W_e[co][ci][tap]; the data gradient swaps the channel roles and mirrors the taps
+      v = p.tflip ? p.w[((long long)ci * p.cin_w + row) * 27 + (26 - tap)] : p.w[((long long)row * p.cin_w + ci) * 27 + tap];
+    }
+    out[j] = from_f32<T>(v);
+  }
+}
+
+// which variant serves (padded source channels, destination channels); 0 = none
+static int stream_variant(int dtype, int taps, int dil, int src_c, int dst_c) {
+  if (dtype != SEUNET_BF16 || taps != 27 || (dil != 1 && dil != 2)) return 0;
+  if (src_c == 8 && dst_c <= 16 && dil == 1) return 3;      // x-folded
+  if (src_c == 16 && dst_c <= 32) return 1;
+  if (src_c == 32 && dst_c <= 16) return 2;
+  return 0;
+}
+bool conv_stream_supported(int dtype, int taps, int dil, int src_c, int dst_c) { return stream_variant(dtype, taps, dil, src_c, dst_c) != 0; }
+
+size_t conv_stream_wpack_bytes(int src_c) { return (size_t)(src_c == 8 ? 9 : 27) * 64 * 16; }
+
+static int stream_zsteps(int planes) {
+  // output planes per workgroup: long marches amortise the 2-plane pipeline fill; 1/3 .. 1/4 of the axis keeps >= 1000
+  // workgroups in flight on a 4 x 128^3 batch.  (zsteps + 2) % 3 == 0 wastes no unrolled step.
+  if (planes <= 40) return planes;
+  const int segs = (planes + 33) / 34;
+  return (planes + segs - 1) / segs;
+}
+int conv_stream_slots(Dims d, int dil) {
+  const int planes = cdiv(d.D, dil);
+  const int zs = stream_zsteps(planes);
+  return cdiv(d.H, ST_TY) * cdiv(d.W, ST_TX) * cdiv(planes, zs) * dil;
+}
+
+int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int src_c, int dst_c, void* wpack, hipStream_t s) {
+  const int cin_e = tflip ? cout_w : cin_w, cout_e = tflip ? cin_w : cout_w;
+  const int var = stream_variant(dtype, 27, 1, src_c, dst_c);
+  SEUNET_CHECK(var != 0 && w && wpack, "conv_stream_pack: unsupported shape (%d -> %d channels)", src_c, dst_c);
+  SEUNET_CHECK(cin_e <= src_c && cout_e <= dst_c, "conv_stream_pack: weight (%d -> %d) exceeds the tensors (%d -> %d)", cin_e, cout_e, src_c, dst_c);
+  StreamPackArgs p{w, wpack, cin_w, cout_w, tflip, cin_e, cout_e, var == 1 ? 32 : 16, var == 3 ? 1 : 0};
+  conv_stream_pack_kernel<bf16_t><<<var == 3 ? 9 : 27, 64, 0, s>>>(p);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int CIN, int COUTP, bool XFOLD, int DIL>
+static int stream_launch_one(const StreamArgs& a, dim3 grid, hipStream_t s) {
+  using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL>;
+  static unsigned long long configured = 0;
+  if (first_use_on_device(configured))
+    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
+  conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL><<<grid, 256, Geo::LDS, s>>>(a);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+// src: [N][D][H][W][src_c] (src_c = 8 | 16 | 32); dst: [N][D][H][W][dst_c], cout valid output channels written
+// (dst_c % 8 == 0, every channel < dst_c is written: channels >= the weight's Cout are zero + bias 0)
+int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
+                       int dst_accumulate, double* stats, Dims d, hipStream_t s) {
+  const int var = stream_variant(dtype, 27, dil, src_c, dst_c);
+  SEUNET_CHECK(var != 0, "conv_stream: unsupported shape (%d -> %d channels, dilation %d, dtype %d)", src_c, dst_c, dil, dtype);
+  SEUNET_CHECK(src && wpack && dst && dst_c % 8 == 0, "conv_stream: bad argument");
+  SEUNET_CHECK((long long)d.vox() * dst_c * 2 < (1LL << 31) && (long long)d.H * d.W * src_c * 2 < (1LL << 31),
+               "conv_stream: one sample exceeds the 32-bit offsets of this kernel");
+  StreamArgs a{};
+  a.src = src; a.wpack = wpack; a.bias = bias; a.dst = dst; a.dstC = dst_c; a.dacc = dst_accumulate; a.cout = dst_c;
+  a.stats = stats; a.zero = device_zero_page();
+  SEUNET_CHECK(a.zero != nullptr, "conv_stream: no zero page on this device");
+  a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
+  const int planes = cdiv(d.D, dil);
+  a.zsteps = stream_zsteps(planes);
+  a.nzseg = cdiv(planes, a.zsteps);
+  a.nyb = cdiv(d.H, ST_TY); a.nxb = cdiv(d.W, ST_TX);
+  SEUNET_CHECK(d.N <= 65535 && a.nzseg * dil <= 65535, "conv_stream: grid too large");
+  dim3 grid(a.nyb * a.nxb, a.nzseg * dil, d.N);
+  if (var == 3) return stream_launch_one<bf16_t, 8, 16, true, 1>(a, grid, s);
+  if (var == 1) return dil == 1 ? stream_launch_one<bf16_t, 16, 32, false, 1>(a, grid, s) : stream_launch_one<bf16_t, 16, 32, false, 2>(a, grid, s);
+  return dil == 1 ? stream_launch_one<bf16_t, 32, 16, false, 1>(a, grid, s) : stream_launch_one<bf16_t, 32, 16, false, 2>(a, grid, s);
+}
+
+}  // namespace seunet

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -129,6 +130,7 @@ struct OpRes {
   size_t raw = 0, raw2 = 0, mean = 0, rstd = 0, mean2 = 0, rstd2 = 0, wp_f = 0, wp_d = 0, wp_x = 0;
   int cin = 0, cout = 0, taps = 0;
   bool need_dgrad = false;
+  bool stream_f = false, stream_d = false;   // forward / data gradient served by the streaming kernel (conv_stream.hip)
 };
 
 struct Plan {
@@ -142,6 +144,7 @@ struct Plan {
   size_t stats, stats2, pgrad, m1, m2, m1b, m2b, wgrad_ws, head_tmp, gx, gx_bytes = 0, xwp = 0, xmom = 0;
   // x-branches (x33 / x63 / x93) recomputed from the <= 2-channel input instead of materialised (csrc/epilogue.hip, XR)
   bool fuse_x = false;
+  bool use_stream = true;
   size_t wgrad_ws_bytes;
   size_t total;
   int stat_slots_max;
@@ -167,6 +170,7 @@ struct Plan {
     }
     size_t gx_max = 0, wg_max = 0, xw_max = 0, xmom_max = 0;
     fuse_x = d.in_channel <= 2 && d.conv_impl != SEUNET_CONV_NAIVE;
+    use_stream = getenv("SEUNET_NO_STREAM") == nullptr;   // (diagnostic switch for A/B timing; the default is on)
     int slots_max = 1, cmax = 8;
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
@@ -185,8 +189,13 @@ struct Plan {
       r.raw = take(act);
       r.mean = take((size_t)d.batch * r.cout * 4);
       r.rstd = take((size_t)d.batch * r.cout * 4);
-      r.wp_f = take(conv_wpack_bytes(d.dtype, r.taps, r.cin, r.cout));
-      if (r.need_dgrad) r.wp_d = take(conv_wpack_bytes(d.dtype, r.taps, r.cout, r.cin));
+      // small-channel 3x3x3 layers with one source tensor (ec1 / ec2 / ec3 / dc6 at width 1) run on the streaming kernel
+      const bool stream_ok = use_stream && o.kind == OP_GATED && o.nsrc == 1 && d.conv_impl != SEUNET_CONV_NAIVE;
+      r.stream_f = stream_ok && conv_stream_supported(d.dtype, 27, o.dil, C[o.src[0]], r.cout);
+      r.stream_d = stream_ok && r.need_dgrad && conv_stream_supported(d.dtype, 27, o.dil, r.cout, C[o.src[0]]);
+      r.wp_f = take(r.stream_f ? conv_stream_wpack_bytes(C[o.src[0]]) : conv_wpack_bytes(d.dtype, r.taps, r.cin, r.cout));
+      if (r.need_dgrad) r.wp_d = take(r.stream_d ? conv_stream_wpack_bytes(r.cout) : conv_wpack_bytes(d.dtype, r.taps, r.cout, r.cin));
+      if (r.stream_f) slots_max = std::max(slots_max, conv_stream_slots(dims[lv], o.dil));
       wg_max = std::max(wg_max, wgrad_workspace_bytes(r.taps, r.cin, r.cout));
       if (o.xname) {
         r.mean2 = take((size_t)d.batch * r.cout * 4);
@@ -269,11 +278,15 @@ struct Exec {
 
   // conv (+ InstanceNorm statistics) of one block: raw <- conv(src), (mean, rstd) <- stats(raw)
   int conv_and_stats(const std::string& nm, int taps, int dil, const SrcList& src, int cin, const float* w, const float* bias, size_t wp_off,
-                     size_t raw_off, int cout, size_t mean_off, size_t rstd_off, const Dims& dm) {
+                     size_t raw_off, int cout, size_t mean_off, size_t rstd_off, const Dims& dm, bool stream = false) {
     DstList dst{};
     dst.n = 1; dst.ptr[0] = at(raw_off); dst.C[0] = cout; dst.acc[0] = 0;
     int slots;
-    if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
+    if (stream) {
+      mark("conv_fwd:" + nm);   // (weights were packed by pack_all_weights)
+      if (int e = launch_conv_stream(p.d.dtype, dil, src.ptr[0], src.C[0], at(wp_off), bias, at(raw_off), cout, 0, dat(p.stats), dm, s)) return e;
+      slots = conv_stream_slots(dm, dil);
+    } else if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
       mark("conv_fwd:" + nm);
       if (int e = launch_conv_naive(p.d.dtype, taps, dil, src, cin, w, 0, bias, dst, dm, s)) return e;
       mark("stats");
@@ -314,12 +327,20 @@ struct Exec {
   // every conv weight of a pass repacked into its MFMA layout by one or two launches (the parameters change every step)
   int pack_all_weights(bool dgrad) {
     if (p.d.conv_impl == SEUNET_CONV_NAIVE) return 0;
+    mark("pack_w");
     std::vector<ConvPackJob> jobs;
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
       if (o.kind != OP_GATED && o.kind != OP_CAT) continue;
       const OpRes& r = p.op[i];
       const std::string n = o.name;
+      if ((!dgrad && r.stream_f) || (dgrad && r.stream_d)) {
+        // PyTorch weight (cout, cin, 3,3,3); the data gradient reads it transposed / mirrored
+        const int src_c = dgrad ? r.cout : p.C[o.src[0]], dst_c = dgrad ? p.C[o.src[0]] : r.cout;
+        if (int e = launch_conv_stream_pack(p.d.dtype, P(n + ".conv1.weight"), r.cin, r.cout, dgrad ? 1 : 0, src_c, dst_c,
+                                            at(dgrad ? r.wp_d : r.wp_f), s)) return e;
+        continue;
+      }
       if (!dgrad) {
         jobs.push_back({P(n + ".conv1.weight"), at(r.wp_f), r.taps, r.cin, r.cout, 0});
         if (o.kind == OP_CAT && o.xname && !p.fuse_x) jobs.push_back({P(std::string(o.xname) + ".conv1.weight"), at(r.wp_x), 1, p.d.in_channel, r.cout, 0});
@@ -327,7 +348,6 @@ struct Exec {
         jobs.push_back({P(n + ".conv1.weight"), at(r.wp_d), r.taps, r.cin, r.cout, 1});
       }
     }
-    mark("pack_w");
     return launch_conv_pack_weights_multi(p.d.dtype, jobs.data(), (int)jobs.size(), s);
   }
 
@@ -349,7 +369,7 @@ struct Exec {
       } else if (o.kind == OP_GATED) {
         const int lv = kT[o.dst].level;
         if (int e = conv_and_stats(n, 27, o.dil, srcs(o), r.cin, P(n + ".conv1.weight"), P(n + ".conv1.bias"), r.wp_f, r.raw,
-                                   r.cout, r.mean, r.rstd, p.dims[lv])) return e;
+                                   r.cout, r.mean, r.rstd, p.dims[lv], r.stream_f)) return e;
         const SseHead hd = sse_head(o, drop1, drop2, !lvl_written[o.head][lv]);
         lvl_written[o.head][lv] = true;
         mark("epi_fwd:" + n);
@@ -422,6 +442,9 @@ struct Exec {
     }
     const float* w = P(n + ".conv1.weight");
     mark("dgrad:" + n);
+    if (r.stream_d)
+      return launch_conv_stream(p.d.dtype, o.dil, at(p.grad[o.dst]), r.cout, at(r.wp_d), nullptr, gd.ptr[0], gd.C[0], gd.acc[0], nullptr,
+                                p.dims[lv], s);
     if (p.d.conv_impl == SEUNET_CONV_NAIVE)
       return launch_conv_naive(p.d.dtype, r.taps, o.dil, gsrc, r.cout, w, 1, nullptr, gd, p.dims[lv], s);
     return launch_conv_igemm(p.d.dtype, r.taps, o.dil, gsrc, r.cout, at(r.wp_d), nullptr, gd, nullptr, p.dims[lv], s);

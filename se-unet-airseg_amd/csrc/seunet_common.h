@@ -178,6 +178,14 @@ int launch_conv_naive(int dtype, int taps, int dil, const SrcList& src, int cin_
                       const float* w_torch, int transpose_flip, const float* bias,
                       const DstList& dst, Dims d, hipStream_t s);
 
+// streaming small-channel 3x3x3 convolution (conv_stream.hip): bf16, 8/16/32 source channels, <= 32 destination channels
+bool conv_stream_supported(int dtype, int taps, int dil, int src_c, int dst_c);
+size_t conv_stream_wpack_bytes(int src_c);
+int conv_stream_slots(Dims d, int dil);
+int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int src_c, int dst_c, void* wpack, hipStream_t s);
+int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
+                       int dst_accumulate, double* stats, Dims d, hipStream_t s);
+
 // weight gradient (wgrad.hip)
 size_t wgrad_workspace_bytes(int taps, int cin, int cout);
 int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy,

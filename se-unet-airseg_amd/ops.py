@@ -99,6 +99,38 @@ def conv3d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[to
     return list(dsts), stats, slots
 
 
+def conv3d_stream(src: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1,
+                  transpose_flip: bool = False, dst: Optional[torch.Tensor] = None, dst_channels: Optional[int] = None,
+                  accumulate: bool = False, want_stats: bool = False):
+    """The streaming small-channel 3x3x3 convolution (csrc/conv_stream.hip): one bf16 source of 8 / 16 / 32 channels.
+    Returns (destination, stats_partial or None, slots)."""
+    lib = _lib.load()
+    code, dims = _code(src), _dims_cl(src)
+    co_w, ci_w = weight.shape[0], weight.shape[1]
+    cout_e = ci_w if transpose_flip else co_w
+    src_c = src.shape[4]
+    dst_c = dst.shape[4] if dst is not None else (dst_channels or (cout_e + 7) // 8 * 8)
+    if not lib.seunet_conv3d_stream_supported(code, dilation, src_c, dst_c):
+        raise RuntimeError(f"conv3d_stream: {src_c} -> {dst_c} channels, dilation {dilation}, dtype {src.dtype} is not served by this kernel")
+    wbuf = torch.empty(lib.seunet_conv3d_stream_wpack_bytes(src_c), dtype=torch.uint8, device=src.device)
+    w = weight.contiguous().float()
+    _lib.check(lib.seunet_conv3d_stream_pack(code, w.data_ptr(), ci_w, co_w, int(transpose_flip), src_c, dst_c, wbuf.data_ptr(), _s()),
+               "conv3d_stream_pack")
+    if dst is None:
+        dst = torch.empty(tuple(src.shape[:4]) + (dst_c,), dtype=src.dtype, device=src.device)
+    stats, slots = None, 0
+    if want_stats:
+        slots = lib.seunet_conv3d_stream_slots(dilation, dims)
+        stats = torch.zeros((dims.n, slots, dst_c, 2), dtype=torch.float64, device=src.device)
+    b = None
+    if bias is not None:
+        b = torch.zeros(dst_c, dtype=torch.float32, device=src.device)
+        b[:bias.numel()] = bias.float()
+    _lib.check(lib.seunet_conv3d_stream(code, dilation, src.data_ptr(), src_c, wbuf.data_ptr(), _lib.ptr(b), dst.data_ptr(), dst_c,
+                                        int(accumulate), _lib.ptr(stats), dims, _s()), "conv3d_stream")
+    return dst, stats, slots
+
+
 def conv3d_wgrad(srcs: Sequence[torch.Tensor], dy: torch.Tensor, cin: int, cout: int, taps: int, dilation: int = 1,
                  impl: int = _lib.CONV_MFMA) -> torch.Tensor:
     lib = _lib.load()

@@ -362,3 +362,61 @@ def test_losses_match_oracle(S):
         assert abs(float(l) - float(l_ref)) < 5e-6, stage
         np.testing.assert_allclose(ag.grad.cpu().numpy(), a.grad.numpy(), rtol=3e-4, atol=1e-9)
         np.testing.assert_allclose(bg.grad.cpu().numpy(), b.grad.numpy(), rtol=3e-4, atol=1e-9)
+
+
+# ---- streaming small-channel convolution (csrc/conv_stream.hip): the full-resolution layers ec1 / ec2 / ec3 / dc6 ----
+STREAM_FWD = [  # (padded source channels, logical cin, cout, dilation)
+    (8, 2, 8, 1),      # ec1: packed network input, x-taps folded into K
+    (8, 8, 16, 1),     # ec2
+    (16, 16, 32, 2),   # ec3
+    (32, 32, 16, 1),   # dc6
+    (16, 16, 32, 1), (32, 32, 16, 2), (16, 16, 8, 2),
+]
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 9, 40), (1, 37, 16, 32), (1, 5, 8, 31), (1, 80, 8, 64)])
+@pytest.mark.parametrize("case", STREAM_FWD)
+def test_conv_stream_forward_and_stats(S, case, shape):
+    """Forward + InstanceNorm partial sums against F.conv3d on bf16-rounded operands; shapes with ragged patches (y, x not
+    multiples of 8 / 32), marches longer than one segment (80 planes) and both z-parity classes of dilation 2."""
+    src_c, cin, cout, dil = case
+    n, d, h, w = shape
+    x = rnd("bf16", gen(n, src_c, d, h, w, seed=2))
+    if cin < src_c:
+        x[:, cin:] = 0
+    wt = rnd("bf16", gen(cout, cin, 3, 3, 3, seed=3, scale=(27 * cin) ** -0.5))
+    b = gen(cout, seed=4, scale=0.1)
+    ref = F.conv3d(x[:, :cin], wt, b, padding=dil, dilation=dil)
+    raw, part, slots = S.conv3d_stream(S.to_cl(x.cuda(), "bf16"), wt.cuda(), b.cuda(), dil, want_stats=True)
+    got = S.from_cl(raw, cout)
+    assert_close(got, ref, "bf16", "conv_stream")
+    mean, rstd = S.stats_finalize(part, slots, d * h * w)
+    rm, rv = ref.mean(dim=(2, 3, 4)), ref.var(dim=(2, 3, 4), unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy()[:, :cout], rm.numpy(), atol=3e-3)
+    np.testing.assert_allclose(rstd.cpu().numpy()[:, :cout], (rv + 1e-5).rsqrt().numpy(), rtol=2e-2)
+    # the same numbers as the tiled implicit-GEMM kernel to bf16 rounding of the stored tensor
+    (raw2,), _, _ = S.conv3d([S.to_cl(x.cuda(), "bf16")], wt.cuda(), b.cuda(), dil, 0, cin=cin)
+    assert float((S.from_cl(raw2, cout) - got).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("acc", [False, True])
+@pytest.mark.parametrize("case", [(16, 8, 8, 1), (32, 16, 16, 2), (16, 32, 32, 1), (16, 8, 16, 1)])   # (dy channels, dx channels, dx tensor channels, dil)
+def test_conv_stream_data_gradient(S, case, acc):
+    """dgrad of ec2 (dy 16 -> dx 8), ec3 (dy 32 -> dx 16, dilation 2), dc6 (dy 16 -> dx 32): the forward weight
+    (cout = dy channels, cin = dx channels) applied transposed / mirrored, optionally += into an existing gradient."""
+    dyc, dxc, dst_c, dil = case
+    n, d, h, w = 2, 7, 10, 36
+    wt = rnd("bf16", gen(dyc, dxc, 3, 3, 3, seed=5, scale=(27 * dxc) ** -0.5))
+    dy = rnd("bf16", gen(n, dyc, d, h, w, seed=6))
+    xx = torch.zeros(n, dxc, d, h, w, requires_grad=True)
+    F.conv3d(xx, wt, padding=dil, dilation=dil).backward(dy)
+    ref = xx.grad
+    old = rnd("bf16", gen(n, dst_c, d, h, w, seed=7)) if acc else None
+    dst = S.to_cl(old.cuda(), "bf16") if acc else None
+    got, _, _ = S.conv3d_stream(S.to_cl(dy.cuda(), "bf16"), wt.cuda(), None, dil, transpose_flip=True, dst=dst, dst_channels=dst_c,
+                                accumulate=acc)
+    g = S.from_cl(got, dxc)
+    want = ref + (old[:, :dxc] if acc else 0)
+    assert_close(g, want, "bf16", "conv_stream dgrad")
+    if dst_c > dxc:
+        assert float(S.from_cl(got)[:, dxc:].abs().max()) == 0.0 or acc
