@@ -7,7 +7,8 @@
 // 8 x 32 (y, x) patch and MARCHES along z:
 //   * input-stationary in z: step s stages ONE input plane and adds its contribution to the three output planes s-1, s,
 //     s+1 (accumulators of three planes live in registers, roles rotate with a 3x unrolled loop), so every LDS fragment
-//     read feeds 3 (dz) x 1-2 (dy) MFMAs instead of one, and the finished plane s-1 is stored while the march goes on;
+//     read feeds 3 (dz) MFMAs instead of one, and the finished plane s-1 is stored while the march goes on; 8 waves, one
+//     output row each, two per SIMD, so that one wave's fragment waits / stores / DMA issue hide behind the other's MFMAs;
 //   * the planes arrive by LDS-DMA (global_load_lds_dwordx4, inline asm so that hipcc neither counts nor drains them) into a
 //     4-slot ring two steps ahead of their use: counted s_waitcnt vmcnt(N) + one raw s_barrier per step, the HBM latency
 //     of a plane is hidden behind two steps of MFMAs; padding voxels read a zero page;
@@ -40,18 +41,25 @@ struct StreamArgs {
   int nyb, nxb, nzseg, zsteps;      // patches, z segments (per parity class), output planes per segment
 };
 
-static constexpr int ST_TY = 8, ST_TX = 32, ST_RING = 4;
+static constexpr int ST_TY = 8, ST_TX = 32, ST_NW = 8;   // 8 waves: one output row each, two waves per SIMD
 
-template <int CIN, int COUTP, bool XFOLD, int DIL> struct StreamGeo {
+template <int CIN, int COUTP, bool XFOLD, int DIL, bool DACC = false> struct StreamGeo {
   static constexpr int NP = CIN / 8;
   static constexpr int HX = ST_TX + 2 * DIL + (XFOLD ? 1 : 0), HY = ST_TY + 2 * DIL;
   static constexpr int NVP = HX * HY, G = (NVP + 63) / 64;
   static constexpr int PS = G * 1024, PLANE = NP * PS;
-  static constexpr int ITEMS = (NP * G + 3) / 4;                 // DMA wave-instructions per wave and plane
+  static constexpr int OLDI = COUTP == 32 ? 2 : 1;             // DMA instructions per old destination row (32 voxels x <= 32 channels x 2 B <= 2 KB)
+  // planes in flight ahead of the one being read: 3 where the 160 KB of LDS allow it; ring = those + the current one + the one
+  // released by the previous step
+  static constexpr int PF = (5 * PLANE + 1280 + (DACC ? 5 * ST_NW * OLDI * 1024 : 0) <= 160 * 1024) ? 3 : 2;
+  static constexpr int RING = PF + 2;
+  static constexpr int ITEMS = (NP * G + ST_NW - 1) / ST_NW;     // DMA wave-instructions per wave and plane
   static constexpr int NB = COUTP == 32 ? 32 : 16, NBX = ST_TX / NB;
   static constexpr int NDX = XFOLD ? 1 : 3, NTAP = 9 * NDX;
-  static constexpr int STORES = COUTP == 32 ? 2 * 4 : 2 * NBX;   // store wave-instructions per wave and step
-  static constexpr int LDS = ST_RING * PLANE + 1024;            // + a 1-KB dump for the padding DMA instructions
+  static constexpr int STORES = COUTP == 32 ? 4 : NBX;           // store wave-instructions per wave and step
+  static constexpr int BIAS = RING * PLANE + 1024;          // f32 bias table (32-channel tiles keep it here instead of 16 registers per lane)
+  static constexpr int OLD = BIAS + 256;                       // old destination rows (gradient accumulation): [ring slots][8 waves][OLDI KB]
+  static constexpr int LDS = OLD + (DACC ? RING * ST_NW * OLDI * 1024 : 0);   // ring + a 1-KB dump for the padding DMA instructions (+ old rows)
 };
 
 __device__ __forceinline__ void stream_dma16(const void* gsrc, unsigned lds_dst) {
@@ -62,10 +70,11 @@ __device__ __forceinline__ void stream_dma16(const void* gsrc, unsigned lds_dst)
 }
 template <int N> __device__ __forceinline__ void stream_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <typename T, int CIN, int COUTP, bool XFOLD, int DIL>
-__global__ void __launch_bounds__(256, 1)
+// FWD: bias + InstanceNorm partial sums (forward); !FWD: data gradient, optionally accumulating into the destination (DACC)
+template <typename T, int CIN, int COUTP, bool XFOLD, int DIL, bool FWD, bool DACC>
+__global__ void __launch_bounds__(512, 2)
 conv_stream_kernel(StreamArgs a) {
-  using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL>;
+  using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL, DACC>;
   constexpr int NP = Geo::NP, HX = Geo::HX, HY = Geo::HY, NVP = Geo::NVP, G = Geo::G, PS = Geo::PS, PLANE = Geo::PLANE;
   constexpr int ITEMS = Geo::ITEMS, NB = Geo::NB, NBX = Geo::NBX, NDX = Geo::NDX, NTAP = Geo::NTAP, STORES = Geo::STORES;
   constexpr int ACCR = COUTP == 32 ? 16 : 4;
@@ -92,12 +101,12 @@ conv_stream_kernel(StreamArgs a) {
   const long long plane_bytes = (long long)a.H * a.W * CIN * (long long)sizeof(T);
   const unsigned char* src_n = reinterpret_cast<const unsigned char*>(a.src) + (long long)n * a.D * plane_bytes;
 
-  // ---- DMA plan: item it of this wave = (piece, 64-voxel group) number wave + 4 * it ----
+  // ---- DMA plan: item it of this wave = (piece, 64-voxel group) number wave + 8 * it ----
   unsigned doff[ITEMS];            // byte offset inside a z-plane of this lane's 16 bytes; 0xFFFFFFFF = padding (zero page)
   unsigned dlds[ITEMS];            // LDS byte offset inside a plane image (wave-uniform)
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
-    const int id = wave + 4 * it;
+    const int id = wave + ST_NW * it;
     const int p = id / G, gi = id % G;
     const int v = gi * 64 + lane;
     const int hy = v / HX, hx = v % HX;
@@ -107,24 +116,43 @@ conv_stream_kernel(StreamArgs a) {
     dlds[it] = (unsigned)(p * PS + gi * 1024);
   }
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
-  auto dma_item = [&](int s, auto it_c) __attribute__((always_inline)) {   // plane of step s -> ring slot s % 4
+  auto dma_item = [&](int s, int slot, auto it_c) __attribute__((always_inline)) {   // plane of step s -> ring slot `slot` (= s % Geo::RING)
     constexpr int it = decltype(it_c)::value;
     if constexpr (it < ITEMS) {
       // every wave issues exactly ITEMS instructions per plane (the vmcnt arithmetic of the march counts on it): an item
       // number beyond the plane's NP * G pieces copies the zero page into the dump area
-      const bool real = wave + 4 * it < NP * G;                     // wave-uniform
+      const bool real = wave + ST_NW * it < NP * G;                 // wave-uniform
       const int pl = q0 - 1 + s;                                    // plane index in the parity class
       const int z = pz + DIL * pl;
       const bool zok = real && pl >= 0 && z < a.D && s < nsteps;    // wave-uniform
       const unsigned char* base = src_n + (long long)(zok ? z : 0) * plane_bytes;
       const unsigned char* gp = (zok && doff[it] != 0xFFFFFFFFu) ? base + doff[it] : zero_page;
-      stream_dma16(gp, real ? lds_base + (unsigned)((s & 3) * PLANE) + dlds[it] : lds_base + (unsigned)(ST_RING * PLANE));
+      stream_dma16(gp, real ? lds_base + (unsigned)(slot * PLANE) + dlds[it] : lds_base + (unsigned)(Geo::RING * PLANE));
     }
   };
-  auto dma_plane = [&](int s) __attribute__((always_inline)) {
+  auto dma_plane = [&](int s, int slot) __attribute__((always_inline)) {
     [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
-      (dma_item(s, std::integral_constant<int, I>{}), ...);
+      (dma_item(s, slot, std::integral_constant<int, I>{}), ...);
     }(std::make_integer_sequence<int, ITEMS>{});
+  };
+
+  // gradient accumulation (DACC): the destination row this wave will finish at step s arrives by one more DMA instruction,
+  // issued with the plane of step s (two steps ahead) into a wave-private 1-KB slot; no register load sits in the march
+  const int old_row_bytes = ST_TX * a.dstC * (int)sizeof(T);        // <= OLDI KB
+  auto dma_old = [&](int s, int slot) __attribute__((always_inline)) {
+    if constexpr (DACC) {
+      const int q = q0 + s - 2, z = pz + DIL * q, y = y0 + wave;
+      const bool rok = q >= q0 && q < q1 && y < a.H;                // wave-uniform
+      const unsigned char* row = reinterpret_cast<const unsigned char*>(a.dst) +
+                                 ((((long long)n * a.D + (rok ? z : 0)) * a.H + (rok ? y : 0)) * a.W + x0) * a.dstC * (long long)sizeof(T);
+#pragma unroll
+      for (int k = 0; k < Geo::OLDI; ++k) {
+        const int byte = k * 1024 + lane * 16;
+        const int xv = x0 + byte / (a.dstC * (int)sizeof(T));
+        const unsigned char* gp = (rok && byte < old_row_bytes && xv < a.W) ? row + byte : zero_page;
+        stream_dma16(gp, lds_base + (unsigned)(Geo::OLD + ((slot * ST_NW + wave) * Geo::OLDI + k) * 1024));
+      }
+    }
   };
 
   // ---- weights: registers for the whole march.  wpack: [tap][lane][8 elements] ----
@@ -139,108 +167,118 @@ conv_stream_kernel(StreamArgs a) {
   // 32x32x16 (COUTP 32): lane = (voxel n = lane & 31, k-half h = lane >> 5): piece h of the voxel
   const int fn = COUTP == 32 ? (lane & 31) : (lane & 15);
   const int fg = COUTP == 32 ? (lane >> 5) : (lane >> 4);
-  // output rows of this wave: ra and ra + DIL (dilation 2: the two rows of one y-parity class share their input rows)
-  const int ra = DIL == 1 ? 2 * wave : (wave >> 1) * 4 + (wave & 1);
-  // LDS byte offset of the lane's fragment for input row index ri = 0..3 (y = ra + DIL * (ri - 1)), x-block xbk, tap dx:
+  // output row of this wave (two waves per SIMD: while one waits for fragments, stores or the barrier the other issues MFMAs)
+  const int ra = wave;
+  // LDS byte offset of the lane's fragment for input row index ri = 0..2 (y = ra + DIL * (ri - 1)), x-block xbk, tap dx:
   //   ((ra + DIL*ri) * HX + xbk*NB + fn + DIL*(dx+1)) * 16 + piece * PS      (halo origin = -DIL in y and x)
   const int frag0 = XFOLD ? ((ra * HX + fn + fg) * 16) : ((ra * HX + fn) * 16 + fg * PS);
 
-  AccT acc[3][2][NBX];
+  AccT acc[3][NBX];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int b = 0; b < NBX; ++b)
 #pragma unroll
-      for (int b = 0; b < NBX; ++b)
-#pragma unroll
-        for (int e = 0; e < ACCR; ++e) acc[i][r][b][e] = 0.f;
+      for (int e = 0; e < ACCR; ++e) acc[i][b][e] = 0.f;
 
   // channel of accumulator register e of this lane
   auto chan = [&](int e) __attribute__((always_inline)) -> int {
     if constexpr (COUTP == 32) return (e & 3) + 8 * (e >> 2) + 4 * fg;
     else return 4 * fg + e;
   };
-  float bias_r[ACCR];
+  constexpr int SR = FWD ? ACCR : 1;
+  constexpr int BR = (FWD && COUTP == 16) ? ACCR : 1;     // bias in registers (16-channel tiles) or in LDS (32-channel tiles)
+  float bias_r[BR];
 #pragma unroll
-  for (int e = 0; e < ACCR; ++e) { const int c = chan(e); bias_r[e] = (a.bias != nullptr && c < a.cout) ? a.bias[c] : 0.f; }
-  // running InstanceNorm sums of this lane: deviations from the lane's first value of each channel (f32)
-  float sh[ACCR], s1[ACCR], s2[ACCR];
-  float cnt = 0.f;
-  bool have_shift = false;
+  for (int e = 0; e < BR; ++e) { const int c = chan(e); bias_r[e] = (FWD && a.bias != nullptr && c < a.cout) ? a.bias[c] : 0.f; }
+  if constexpr (FWD && COUTP == 32) {
+    if (tid < 32) reinterpret_cast<float*>(smem + Geo::BIAS)[tid] = (a.bias != nullptr && tid < a.cout) ? a.bias[tid] : 0.f;
+    __syncthreads();
+  }
+  // running InstanceNorm sums of this lane (f32: at most ~40 values per lane and channel; the per-lane totals are combined in
+  // f64.  bf16 activations keep 8 mantissa bits, the gate for this mode is the bf16-autocast comparison)
+  float s1[SR], s2[SR];
 #pragma unroll
-  for (int e = 0; e < ACCR; ++e) { sh[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+  for (int e = 0; e < SR; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
   // destination: buffer descriptor over this sample (range-checked 32-bit offsets; padding voxels use an offset beyond it)
   const long long dst_sample = (long long)a.D * a.H * a.W * a.dstC * (long long)sizeof(T);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<unsigned char*>(a.dst) + (long long)n * dst_sample, 0, (int)dst_sample, 0x00020000);
 
-  // ---- one step: input plane of step S (ring slot S & 3) -> accumulators; PH = S % 3 ----
-  auto compute = [&](int s, auto ph_c) __attribute__((always_inline)) {
+  // ---- one step: input plane of step s (ring slot `slot`) -> accumulators; PH = s % 3 ----
+  // The fragments of input row ri + 1 are requested before the MFMAs of row ri issue (two register sets), and the prefetch
+  // DMA instructions of the plane Geo::PF steps ahead are spread over the rows.
+  auto compute = [&](int s, int slot, int slot_pf, auto ph_c) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_c)::value;
-    const unsigned char* pl = smem + (s & 3) * PLANE;
+    const unsigned char* pl = smem + slot * PLANE;
+    bf16x8 fr[2][NDX][NBX];
+    auto load_row = [&](auto ri_c) __attribute__((always_inline)) {
+      constexpr int ri = decltype(ri_c)::value;
+      if constexpr (ri < 3) {
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
+        for (int dxi = 0; dxi < NDX; ++dxi)
 #pragma unroll
-      for (int dxi = 0; dxi < NDX; ++dxi) {
-        bf16x8 fr[NBX];
+          for (int b = 0; b < NBX; ++b) {
+            const int off = frag0 + ((DIL * ri) * HX + b * NB + (XFOLD ? 0 : DIL * dxi)) * 16;
+            fr[ri & 1][dxi][b] = *reinterpret_cast<const bf16x8*>(pl + off);
+          }
+      }
+    };
+    load_row(std::integral_constant<int, 0>{});
+    [&]<int... RI>(std::integer_sequence<int, RI...>) __attribute__((always_inline)) {
+      ([&]() __attribute__((always_inline)) {
+        constexpr int ri = RI;                             // input row y = ra + DIL * (ri - 1): tap dy = ri - 1
+        load_row(std::integral_constant<int, ri + 1>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+          (((I % 3) == ri ? dma_item(s + Geo::PF, slot_pf, std::integral_constant<int, I>{}) : (void)0), ...);
+        }(std::make_integer_sequence<int, ITEMS>{});
+        if (ri == 2) dma_old(s + Geo::PF, slot_pf);
+        __builtin_amdgcn_sched_barrier(0);                 // (the next row's reads stay ahead of this row's MFMAs)
 #pragma unroll
-        for (int b = 0; b < NBX; ++b) {
-          const int off = frag0 + ((DIL * ri) * HX + b * NB + (XFOLD ? 0 : DIL * dxi)) * 16;
-          fr[b] = *reinterpret_cast<const bf16x8*>(pl + off);
-        }
+        for (int dxi = 0; dxi < NDX; ++dxi)
 #pragma unroll
-        for (int ro = 0; ro < 2; ++ro) {                 // output row ra + DIL*ro uses input row ri with dy = ri - 1 - ro
-          const int dy = ri - 1 - ro;
-          if (dy < -1 || dy > 1) continue;
-#pragma unroll
-          for (int dz = -1; dz <= 1; ++dz) {             // output plane s - dz
+          for (int dz = -1; dz <= 1; ++dz) {               // output plane s - dz
             const int ai = (PH - dz + 3) % 3;
-            const int tap = ((dz + 1) * 3 + (dy + 1)) * NDX + dxi;
+            const int tap = ((dz + 1) * 3 + ri) * NDX + dxi;
 #pragma unroll
             for (int b = 0; b < NBX; ++b) {
               if constexpr (COUTP == 32)
-                acc[ai][ro][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap], fr[b], acc[ai][ro][b], 0, 0, 0);
+                acc[ai][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b], 0, 0, 0);
               else
-                acc[ai][ro][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap], fr[b], acc[ai][ro][b], 0, 0, 0);
+                acc[ai][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b], 0, 0, 0);
             }
           }
-        }
-      }
-      // the prefetch of the plane two steps ahead, spread over the MFMA block: items ri, ri + 4 after input row ri
-      [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
-        (((I % 4) == ri ? dma_item(s + 2, std::integral_constant<int, I>{}) : (void)0), ...);
-      }(std::make_integer_sequence<int, ITEMS>{});
-    }
+        __builtin_amdgcn_sched_barrier(0);
+      }(), ...);
+    }(std::make_integer_sequence<int, 3>{});
   };
 
   // ---- epilogue of the finished output plane q = (q0 - 1 + s) - 1 held in acc[(PH + 2) % 3] ----
-  auto finish = [&](int s, auto ph_c) __attribute__((always_inline)) {
+  auto finish = [&](int s, int slot, auto ph_c) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_c)::value;
     constexpr int ai = (PH + 2) % 3;
     const int q = q0 + s - 2;                                       // parity-class plane index
     const int z = pz + DIL * q;
     const bool zok = q >= q0 && q < q1;                             // wave-uniform
-#pragma unroll
-    for (int ro = 0; ro < 2; ++ro) {
-      const int y = y0 + ra + DIL * ro;
+    {
+      const int y = y0 + ra;
 #pragma unroll
       for (int b = 0; b < NBX; ++b) {
         const int x = x0 + b * NB + fn;
         const bool ok = zok && y < a.H && x < a.W;
         float v[ACCR];
 #pragma unroll
-        for (int e = 0; e < ACCR; ++e) v[e] = acc[ai][ro][b][e] + bias_r[e];
-        if (a.stats != nullptr) {
-          if (ok && !have_shift) {
+        for (int e = 0; e < ACCR; ++e) {
+          float bv = 0.f;
+          if constexpr (FWD && COUTP == 16) bv = bias_r[BR == 1 ? 0 : e];
+          if constexpr (FWD && COUTP == 32) bv = reinterpret_cast<const float*>(smem + Geo::BIAS)[(e & 3) + 8 * (e >> 2) + 4 * fg];
+          v[e] = acc[ai][b][e] + bv;
+        }
+        if constexpr (FWD) {
+          if (ok) {                      // (a.stats == nullptr: the sums are simply never stored)
 #pragma unroll
-            for (int e = 0; e < ACCR; ++e) sh[e] = v[e];
-          }
-          have_shift = have_shift || ok;
-          if (ok) {
-            cnt += 1.f;
-#pragma unroll
-            for (int e = 0; e < ACCR; ++e) { const float d = v[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+            for (int e = 0; e < ACCR; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
           }
         }
         const unsigned vox = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
@@ -251,8 +289,9 @@ conv_stream_kernel(StreamArgs a) {
           const bool cok = ok && c0 < a.cout;
           const unsigned off = cok ? (vox * (unsigned)a.dstC + (unsigned)c0) * (unsigned)sizeof(T) : 0x80000000u;   // beyond the sample: dropped
           float w4[4] = {v[4 * pc], v[4 * pc + 1], v[4 * pc + 2], v[4 * pc + 3]};
-          if (a.dacc) {
-            const u32x2s o = __builtin_amdgcn_raw_buffer_load_b64(rd, off, 0, 0);
+          if constexpr (DACC) {
+            const u32x2s o = *reinterpret_cast<const u32x2s*>(smem + Geo::OLD + (slot * ST_NW + wave) * Geo::OLDI * 1024 +
+                                                               ((b * NB + fn) * a.dstC + c0) * (int)sizeof(T));
             w4[0] += bf16_bits_to_f32(o.x & 0xffffu); w4[1] += bf16_bits_to_f32(o.x >> 16);
             w4[2] += bf16_bits_to_f32(o.y & 0xffffu); w4[3] += bf16_bits_to_f32(o.y >> 16);
           }
@@ -262,28 +301,36 @@ conv_stream_kernel(StreamArgs a) {
           __builtin_amdgcn_raw_buffer_store_b64(u, rd, off, 0, 0);
         }
 #pragma unroll
-        for (int e = 0; e < ACCR; ++e) acc[ai][ro][b][e] = 0.f;
+        for (int e = 0; e < ACCR; ++e) acc[ai][b][e] = 0.f;
       }
     }
   };
 
   // ---- the march ----
-  constexpr int LW = ITEMS;      // DMA instructions per wave and plane (waves with fewer real items are padded below)
-  dma_plane(0);
-  dma_plane(1);
-  stream_wait_vm<LW>();          // plane 0 has landed (this wave's part); plane 1 may be in flight
+  // VMEM issue order of a wave: [prologue: DMA(0) .. DMA(PF-1)]  then per step s: DMA(s+PF) (inside compute), stores(s).
+  // At the top of step s >= 1 plane s must have landed; younger than it are DMA(s+1) .. DMA(s+PF-1) and the stores of up to
+  // three steps: waiting for all but (PF-1) * LW + STORES operations is sufficient from step 1 on (and asks the stores of
+  // steps <= s-2, a full step old, to be done).  Then one barrier: every wave's part of the plane is in LDS, and every wave
+  // has finished reading the slot that this step's prefetch overwrites (ring = PF + 2 slots).
+  constexpr int LW = ITEMS + (DACC ? Geo::OLDI : 0);   // DMA instructions per wave and step (padded to the same count in every wave)
+#pragma unroll
+  for (int k = 0; k < Geo::PF; ++k) { dma_plane(k, k); dma_old(k, k); }
+  stream_wait_vm<(Geo::PF - 1) * LW>();    // plane 0 has landed (this wave's part)
   __builtin_amdgcn_s_barrier();
+  int slot = 0, slot_pf = Geo::PF;         // s % Geo::RING, (s + Geo::PF) % Geo::RING
   for (int s0 = 0; s0 < nsteps; s0 += 3) {
     [&]<int... PH>(std::integer_sequence<int, PH...>) __attribute__((always_inline)) {
       ([&]() __attribute__((always_inline)) {
         const int s = s0 + PH;
         if (s < nsteps) {
           if (s > 0) {
-            stream_wait_vm<LW + STORES>();   // only the prefetch and the stores issued during the previous step may be in flight: plane s has landed
+            stream_wait_vm<(Geo::PF - 1) * LW + STORES>();
             __builtin_amdgcn_s_barrier();
           }
-          compute(s, std::integral_constant<int, PH>{});
-          finish(s, std::integral_constant<int, PH>{});
+          compute(s, slot, slot_pf, std::integral_constant<int, PH>{});
+          finish(s, slot, std::integral_constant<int, PH>{});
+          slot = slot == Geo::RING - 1 ? 0 : slot + 1;
+          slot_pf = slot_pf == Geo::RING - 1 ? 0 : slot_pf + 1;
         }
       }(), ...);
     }(std::make_integer_sequence<int, 3>{});
@@ -291,16 +338,14 @@ conv_stream_kernel(StreamArgs a) {
 
   // ---- InstanceNorm partial sums of this workgroup: un-shift in f64, reduce over the lanes that hold the same channels,
   //      then over the four waves (fixed order), one record per workgroup ----
-  if (a.stats != nullptr) {
+  if (FWD && a.stats != nullptr) {
     stream_wait_vm<0>();
     __syncthreads();             // the ring is dead: reuse its first bytes
-    double* red = reinterpret_cast<double*>(smem);     // [4 waves][COUTP][2]
-    const double dc = (double)cnt;
+    double* red = reinterpret_cast<double*>(smem);     // [8 waves][COUTP][2]
 #pragma unroll
     for (int e = 0; e < ACCR; ++e) {
-      const double d0 = (double)sh[e];
-      double t1 = (double)s1[e] + dc * d0;
-      double t2 = (double)s2[e] + 2.0 * d0 * (double)s1[e] + dc * d0 * d0;
+      double t1 = (double)s1[FWD ? e : 0];
+      double t2 = (double)s2[FWD ? e : 0];
       constexpr int GROUP = COUTP == 32 ? 32 : 16;
 #pragma unroll
       for (int off = 1; off < GROUP; off <<= 1) { t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
@@ -314,8 +359,9 @@ conv_stream_kernel(StreamArgs a) {
     if (tid < COUTP * 2) {
       const int c = tid >> 1, k = tid & 1;
       if (c < a.cout) {
-        const double tot = ((red[(0 * COUTP + c) * 2 + k] + red[(1 * COUTP + c) * 2 + k]) + red[(2 * COUTP + c) * 2 + k]) +
-                           red[(3 * COUTP + c) * 2 + k];
+        double tot = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < ST_NW; ++wv) tot += red[(wv * COUTP + c) * 2 + k];      // fixed order
         const long long slot = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         const long long slots = (long long)gridDim.y * gridDim.x;
         a.stats[(((long long)n * slots + slot) * a.cout + c) * 2 + k] = tot;
@@ -392,16 +438,25 @@ int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, in
   return 0;
 }
 
-template <typename T, int CIN, int COUTP, bool XFOLD, int DIL>
-static int stream_launch_one(const StreamArgs& a, dim3 grid, hipStream_t s) {
-  using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL>;
+template <typename T, int CIN, int COUTP, bool XFOLD, int DIL, bool FWD, bool DACC>
+static int stream_launch_acc(const StreamArgs& a, dim3 grid, hipStream_t s) {
+  using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL, DACC>;
   static unsigned long long configured = 0;
   if (first_use_on_device(configured))
-    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL>),
+    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL, FWD, DACC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
-  conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL><<<grid, 256, Geo::LDS, s>>>(a);
+  conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL, FWD, DACC><<<grid, ST_NW * 64, Geo::LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;
+}
+template <typename T, int CIN, int COUTP, bool XFOLD, int DIL>
+static int stream_launch_one(const StreamArgs& a, dim3 grid, hipStream_t s) {
+  if (a.bias != nullptr || a.stats != nullptr) {
+    SEUNET_CHECK(!a.dacc, "conv_stream: accumulation into the destination is a data-gradient feature (no bias, no statistics)");
+    return stream_launch_acc<T, CIN, COUTP, XFOLD, DIL, true, false>(a, grid, s);
+  }
+  return a.dacc ? stream_launch_acc<T, CIN, COUTP, XFOLD, DIL, false, true>(a, grid, s)
+                : stream_launch_acc<T, CIN, COUTP, XFOLD, DIL, false, false>(a, grid, s);
 }
 
 // src: [N][D][H][W][src_c] (src_c = 8 | 16 | 32); dst: [N][D][H][W][dst_c], cout valid output channels written
