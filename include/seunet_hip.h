@@ -63,6 +63,12 @@ int seunet_conv3d_stream_pack(int dtype, const float* w, int cin_w, int cout_w, 
                               seunet_stream_t s);
 int seunet_conv3d_stream(int dtype, int dilation, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
                          int dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s);
+/* weight gradient of the same small-channel layers on the streaming structure (csrc/wgrad_stream.hip): x (x_c = 8 | 16 | 32
+ * channels, cin of them carry weights), dy (dy_c channels, cout valid); dw: (cout, cin, 3, 3, 3) f32, overwritten. */
+int seunet_conv3d_wgrad_stream_supported(int dtype, int dilation, int x_c, int dy_c);
+size_t seunet_conv3d_wgrad_stream_workspace_bytes(int x_c, int dy_c, int dilation, seunet_dims dims);
+int seunet_conv3d_wgrad_stream(int dtype, int dilation, const void* x, int x_c, int cin, const void* dy, int dy_c, int cout, float* dw,
+                               void* workspace, size_t workspace_bytes, seunet_dims dims, seunet_stream_t s);
 size_t seunet_conv3d_wgrad_workspace_bytes(int taps, int cin, int cout);
 int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c,
                         int cin, const void* dy, int cout, float* dw, void* workspace, size_t workspace_bytes,

@@ -73,6 +73,14 @@ int seunet_conv3d_stream(int dtype, int dilation, const void* src, int src_c, co
                          int dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s) {
   return launch_conv_stream(dtype, dilation, src, src_c, wpack, bias, dst, dst_c, dst_accumulate, stats_partial, D(dims), S(s));
 }
+int seunet_conv3d_wgrad_stream_supported(int dtype, int dilation, int x_c, int dy_c) { return wgrad_stream_supported(dtype, 27, dilation, x_c, dy_c) ? 1 : 0; }
+size_t seunet_conv3d_wgrad_stream_workspace_bytes(int x_c, int dy_c, int dilation, seunet_dims dims) {
+  return wgrad_stream_workspace_bytes(x_c, dy_c, dilation, D(dims));
+}
+int seunet_conv3d_wgrad_stream(int dtype, int dilation, const void* x, int x_c, int cin, const void* dy, int dy_c, int cout, float* dw,
+                               void* workspace, size_t workspace_bytes, seunet_dims dims, seunet_stream_t s) {
+  return launch_wgrad_stream(dtype, dilation, x, x_c, cin, dy, dy_c, cout, dw, workspace, workspace_bytes, D(dims), S(s));
+}
 size_t seunet_conv3d_wgrad_workspace_bytes(int taps, int cin, int cout) { return wgrad_workspace_bytes(taps, cin, cout); }
 int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, const void* const* src, const int* src_c, int cin,
                         const void* dy, int cout, float* dw, void* workspace, size_t workspace_bytes, seunet_dims dims,

@@ -130,7 +130,7 @@ struct OpRes {
   size_t raw = 0, raw2 = 0, mean = 0, rstd = 0, mean2 = 0, rstd2 = 0, wp_f = 0, wp_d = 0, wp_x = 0;
   int cin = 0, cout = 0, taps = 0;
   bool need_dgrad = false;
-  bool stream_f = false, stream_d = false;   // forward / data gradient served by the streaming kernel (conv_stream.hip)
+  bool stream_f = false, stream_d = false, stream_w = false;   // forward / data gradient / weight gradient on the streaming kernels
 };
 
 struct Plan {
@@ -196,6 +196,8 @@ struct Plan {
       r.wp_f = take(r.stream_f ? conv_stream_wpack_bytes(C[o.src[0]]) : conv_wpack_bytes(d.dtype, r.taps, r.cin, r.cout));
       if (r.need_dgrad) r.wp_d = take(r.stream_d ? conv_stream_wpack_bytes(r.cout) : conv_wpack_bytes(d.dtype, r.taps, r.cout, r.cin));
       if (r.stream_f) slots_max = std::max(slots_max, conv_stream_slots(dims[lv], o.dil));
+      r.stream_w = stream_ok && wgrad_stream_supported(d.dtype, 27, o.dil, C[o.src[0]], r.cout);
+      if (r.stream_w) wg_max = std::max(wg_max, wgrad_stream_workspace_bytes(C[o.src[0]], r.cout, o.dil, dims[lv]));
       wg_max = std::max(wg_max, wgrad_workspace_bytes(r.taps, r.cin, r.cout));
       if (o.xname) {
         r.mean2 = take((size_t)d.batch * r.cout * 4);
@@ -421,7 +423,10 @@ struct Exec {
     const int wi = find_param(reg, n + ".conv1.weight");
     if (grads[wi]) {
       mark("wgrad:" + n);
-      if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
+      if (r.stream_w) {
+        if (int e = launch_wgrad_stream(p.d.dtype, o.dil, x.ptr[0], x.C[0], r.cin, at(p.grad[o.dst]), r.cout, r.cout, grads[wi],
+                                        at(p.wgrad_ws), p.wgrad_ws_bytes, p.dims[lv], s)) return e;
+      } else if (p.d.conv_impl == SEUNET_CONV_NAIVE) {
         if (int e = launch_wgrad_naive(p.d.dtype, r.taps, o.dil, x, r.cin, at(p.grad[o.dst]), r.cout, grads[wi], p.dims[lv], s)) return e;
       } else {
         if (int e = launch_wgrad(p.d.dtype, r.taps, o.dil, x, r.cin, at(p.grad[o.dst]), r.cout, grads[wi], at(p.wgrad_ws),

@@ -186,6 +186,12 @@ int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, in
 int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
                        int dst_accumulate, double* stats, Dims d, hipStream_t s);
 
+// streaming small-channel weight gradient (wgrad_stream.hip)
+bool wgrad_stream_supported(int dtype, int taps, int dil, int x_c, int dy_c);
+size_t wgrad_stream_workspace_bytes(int x_c, int dy_c, int dil, Dims d);
+int launch_wgrad_stream(int dtype, int dil, const void* x, int x_c, int cin_w, const void* dy, int dy_c, int cout_w, float* dw,
+                        void* workspace, size_t ws_bytes, Dims d, hipStream_t s);
+
 // weight gradient (wgrad.hip)
 size_t wgrad_workspace_bytes(int taps, int cin, int cout);
 int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy,

@@ -145,6 +145,20 @@ def conv3d_wgrad(srcs: Sequence[torch.Tensor], dy: torch.Tensor, cin: int, cout:
     return dw
 
 
+def conv3d_wgrad_stream(x: torch.Tensor, dy: torch.Tensor, cin: int, cout: int, dilation: int = 1) -> torch.Tensor:
+    """Weight gradient on the streaming kernel (csrc/wgrad_stream.hip): x (N,D,H,W,8|16|32) bf16, dy (N,D,H,W,C) bf16."""
+    lib = _lib.load()
+    code, dims = _code(dy), _dims_cl(dy)
+    if not lib.seunet_conv3d_wgrad_stream_supported(code, dilation, x.shape[4], dy.shape[4]):
+        raise RuntimeError(f"conv3d_wgrad_stream: {x.shape[4]} x {dy.shape[4]} channels, dilation {dilation} is not served by this kernel")
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dy.device)
+    nbytes = lib.seunet_conv3d_wgrad_stream_workspace_bytes(x.shape[4], dy.shape[4], dilation, dims)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    _lib.check(lib.seunet_conv3d_wgrad_stream(code, dilation, x.data_ptr(), x.shape[4], cin, dy.data_ptr(), dy.shape[4], cout,
+                                              dw.data_ptr(), ws.data_ptr(), nbytes, dims, _s()), "conv3d_wgrad_stream")
+    return dw
+
+
 # ---- statistics -----------------------------------------------------------------------------------
 def channel_stats(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
     lib = _lib.load()

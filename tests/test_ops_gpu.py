@@ -420,3 +420,25 @@ def test_conv_stream_data_gradient(S, case, acc):
     assert_close(g, want, "bf16", "conv_stream dgrad")
     if dst_c > dxc:
         assert float(S.from_cl(got)[:, dxc:].abs().max()) == 0.0 or acc
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 9, 40), (1, 37, 16, 32), (1, 5, 8, 31), (1, 80, 8, 64)])
+@pytest.mark.parametrize("case", [(8, 2, 8, 1), (8, 8, 16, 1), (16, 16, 32, 2), (32, 32, 16, 1), (16, 16, 32, 1), (16, 16, 16, 2), (8, 8, 16, 2)])
+def test_conv_stream_weight_gradient(S, case, shape):
+    """dW of ec1 (2 of 8 packed channels -> 8), ec2 (8 -> 16), ec3 (16 -> 32, dilation 2), dc6 (32 -> 16) on the streaming
+    kernel against autograd on bf16-rounded operands, ragged patches and marches longer than one segment included."""
+    x_c, cin, cout, dil = case
+    n, d, h, w = shape
+    x = rnd("bf16", gen(n, x_c, d, h, w, seed=8))
+    if cin < x_c:
+        x[:, cin:] = 0
+    dy = rnd("bf16", gen(n, cout, d, h, w, seed=9))
+    wt = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(x[:, :cin], wt, padding=dil, dilation=dil).backward(dy)
+    got = S.conv3d_wgrad_stream(S.to_cl(x.cuda(), "bf16"), S.to_cl(dy.cuda(), "bf16"), cin, cout, dil)
+    assert got.shape == wt.grad.shape
+    err = float((got.cpu() - wt.grad).abs().max())
+    assert err <= 2e-3 * float(wt.grad.abs().max()) + 1e-4, (err, float(wt.grad.abs().max()))
+    # and the tiled kernel's answer on the same operands
+    ref2 = S.conv3d_wgrad([S.to_cl(x.cuda(), "bf16")], S.to_cl(dy.cuda(), "bf16"), cin, cout, 27, dil)
+    assert float((got - ref2).abs().max()) <= 2e-3 * float(wt.grad.abs().max()) + 1e-4
