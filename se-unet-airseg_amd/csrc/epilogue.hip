@@ -15,14 +15,18 @@
 // instead of read, its statistics come from the input's second moments, and its weight gradient is accumulated in the
 // backward pass B (XR / XW template modes below).
 #include "seunet_common.h"
+#include <type_traits>
 
 namespace seunet {
 
 static constexpr int EPI_THREADS = 256;
 
 int epi_partials(Dims d) {
+  // One partial record per block and sample.  128 voxels per block at least: the coarse levels (32^3, 16^3) were running
+  // pass A on 4..32 blocks per sample, 32 dependent iterations each (36 us for a 16^3 x 64-channel tensor).  256 at most
+  // (every record is summed again by the finalize kernels: 512 made those 30 % slower for nothing).
   long long v = d.vox();
-  long long p = v / 1024;
+  long long p = v / 128;
   if (p < 1) p = 1;
   if (p > 256) p = 256;
   return (int)p;
@@ -214,13 +218,16 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   }
   // f64 sums live in thread-private LDS slots (pass A only): 32 fewer VGPRs than register accumulators, which is
   // the difference between 2 and 3 waves per SIMD for this latency-bound loop
-  __shared__ double acc64[APPLY ? 1 : 16][APPLY ? 1 : EPI_THREADS];
+  // bf16 activations: the thread's <= ~130 voxels are summed in f32 registers and converted once (the tensors keep 8
+  // mantissa bits; gate = the bf16-autocast comparison), which frees the 32 KB of LDS slots -> twice the blocks per CU
+  constexpr bool F64ACC = !APPLY && sizeof(T) == 4;
+  __shared__ double acc64[F64ACC ? 16 : 1][F64ACC ? EPI_THREADS : 1];
   float fdx[8], fdxx[8];   // f32 staging of the f64 sums, flushed every 8 voxels
   float awse[8], awse2[8], aw20[8], aw21[8], am1[8], am2[8];
   int since_flush = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (!APPLY) acc64[j][threadIdx.x] = acc64[8 + j][threadIdx.x] = 0.0;
+    if (F64ACC) acc64[j][threadIdx.x] = acc64[8 + j][threadIdx.x] = 0.0;
     fdx[j] = fdxx[j] = 0.f;
     awse[j] = awse2[j] = aw20[j] = aw21[j] = 0.f;
     am1[j] = APPLY ? m1p[n * C + c0 + j] : 0.f;
@@ -316,7 +323,7 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       }
     }
     if (APPLY) store8(dxhat_out + vi * C + c0, dxh);
-    else if (++since_flush == 8) {
+    else if (F64ACC && ++since_flush == 8) {
       since_flush = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -331,8 +338,8 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   double sdx[8], sdxx[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sdx[j] = acc64[j][threadIdx.x] + (double)fdx[j];
-    sdxx[j] = acc64[8 + j][threadIdx.x] + (double)fdxx[j];
+    sdx[j] = (F64ACC ? acc64[j][threadIdx.x] : 0.0) + (double)fdx[j];
+    sdxx[j] = (F64ACC ? acc64[8 + j][threadIdx.x] : 0.0) + (double)fdxx[j];
   }
 
   // ---- block reduction (fixed order) ----
@@ -563,7 +570,8 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
   constexpr int VPB = EPI_THREADS / LPV;
   const int c0 = cg * 8;
   float mu[8], rs[8], mu2[8], rs2[8], a1[8], a2[8], b1[8], b2[8];
-  double s[4][8];
+  typedef typename std::conditional<sizeof(T) == 2, float, double>::type SumT;   // (bf16: f32 thread sums, see sse_bwd_kernel)
+  SumT s[4][8];
   float xw[8][2], wa[8], wb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -608,7 +616,7 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
       const float xh = (x[j] - mu[j]) * rs[j];
       d[j] = gy[j] * (xh > 0.f ? 1.f : slope);
       if (APPLY) d[j] = rs[j] * (d[j] - a1[j] - xh * a2[j]);
-      else { s[0][j] += (double)d[j]; s[1][j] += (double)d[j] * (double)xh; }
+      else { s[0][j] += (SumT)d[j]; s[1][j] += (SumT)d[j] * (SumT)xh; }
     }
     if (TWO) {
       float d2[8];
@@ -617,7 +625,7 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
         const float xh = (x2[j] - mu2[j]) * rs2[j];
         d2[j] = gy[j] * (xh > 0.f ? 1.f : slope);
         if (APPLY) d2[j] = rs2[j] * (d2[j] - b1[j] - xh * b2[j]);
-        else { s[2][j] += (double)d2[j]; s[3][j] += (double)d2[j] * (double)xh; }
+        else { s[2][j] += (SumT)d2[j]; s[3][j] += (SumT)d2[j] * (SumT)xh; }
       }
       if (APPLY && !XW) store8(dxhat2_out + o, d2);
       if (XW) {
@@ -658,7 +666,7 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const double r = stride_sum_d<LPV>(s[q][j]);
+      const double r = stride_sum_d<LPV>((double)s[q][j]);
       if (lane < LPV) red[wave][lane][q * 8 + j] = r;
     }
   __syncthreads();

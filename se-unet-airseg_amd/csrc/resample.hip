@@ -176,6 +176,91 @@ __global__ void upsample2_fwd_kernel(const T* __restrict__ in, int C, T* __restr
   }
 }
 
+// Tiled separable form (the one the network uses).  The kernel above issues 8 16-byte loads per stored 16 bytes and is bound
+// by the texture path (0.36 ms for the 32-channel 64^3 -> 128^3 map, 1.7 TB/s).  Here a block produces the 2 x 2 output
+// rows (zo, yo) in {2zb, 2zb+1} x {2yb, 2yb+1} over 128 fine x: phase A blends the <= 3 x 3 coarse (z, y) rows those four
+// output rows draw on -- each coarse 16-byte piece is loaded ONCE per block -- into four z/y-interpolated coarse rows in LDS
+// (f32); phase B interpolates along x from LDS and stores coalesced: ~1.2 loads per store instead of 8.
+constexpr int UF_XF = 128, UF_XC = 68;   // fine x per block; coarse x a block can touch (128 * 63/127 + 2 < 68)
+template <typename T>
+__global__ void __launch_bounds__(256)
+upsample2_fwd_tiled_kernel(const T* __restrict__ in, int C, T* __restrict__ out, int D, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float uf[];   // [4 rows][UF_XC][C]
+  const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
+  const int xf0 = blockIdx.x * UF_XF;
+  const int nxf = (Wo - xf0 < UF_XF) ? Wo - xf0 : UF_XF;
+  const int yb = blockIdx.y, zb = blockIdx.z % D;
+  const long long n = blockIdx.z / D;
+  // coarse rows and weights of the two zo / yo of this block
+  int zs[2][2], ys[2][2]; float lzs[2], lys[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    ac_src(2 * zb + k, rz, D, zs[k][0], zs[k][1], lzs[k]);
+    ac_src(2 * yb + k, ry, H, ys[k][0], ys[k][1], lys[k]);
+  }
+  const int zc0 = zs[0][0], nzc = zs[1][1] - zc0 + 1;         // distinct coarse z: zc0 .. zc0 + nzc - 1 (<= 3)
+  const int yc0 = ys[0][0], nyc = ys[1][1] - yc0 + 1;
+  int xc0, xc1, t0, t1; float tl;
+  ac_src(xf0, rx, W, xc0, t0, tl);
+  ac_src(xf0 + nxf - 1, rx, W, t1, xc1, tl);
+  const int nxc = xc1 - xc0 + 1;                               // <= UF_XC
+  // phase A
+  for (int item = threadIdx.x; item < nxc * G; item += 256) {
+    const int g = item % G, xi = item / G;
+    float acc[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+    for (int zi = 0; zi < nzc; ++zi) {
+      const int z = zc0 + zi;
+      float wz[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) wz[k] = (zs[k][0] == z ? 1.f - lzs[k] : 0.f) + (zs[k][1] == z ? lzs[k] : 0.f);
+      for (int yi = 0; yi < nyc; ++yi) {
+        const int y = yc0 + yi;
+        float v[8];
+        load8(in + ((((n * D + z) * H + y) * W + (xc0 + xi)) * (long long)C) + g * 8, v);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float wy = (ys[k][0] == y ? 1.f - lys[k] : 0.f) + (ys[k][1] == y ? lys[k] : 0.f);
+#pragma unroll
+          for (int kz = 0; kz < 2; ++kz) {
+            const float w = wz[kz] * wy;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[kz * 2 + k][j] += w * v[j];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* q = uf + ((r * UF_XC + xi) * C) + g * 8;
+      reinterpret_cast<float4*>(q)[0] = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+      reinterpret_cast<float4*>(q)[1] = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
+    }
+  }
+  __syncthreads();
+  // phase B
+  for (int item = threadIdx.x; item < 4 * nxf * G; item += 256) {
+    const int g = item % G;
+    int r2 = item / G;
+    const int xo = xf0 + r2 % nxf, r = r2 / nxf;                // r = kz * 2 + ky
+    int x0, x1; float lx;
+    ac_src(xo, rx, W, x0, x1, lx);
+    const float* q0 = uf + ((r * UF_XC + (x0 - xc0)) * C) + g * 8;
+    const float* q1 = uf + ((r * UF_XC + (x1 - xc0)) * C) + g * 8;
+    const float4 a0 = reinterpret_cast<const float4*>(q0)[0], b0 = reinterpret_cast<const float4*>(q0)[1];
+    const float4 a1 = reinterpret_cast<const float4*>(q1)[0], b1 = reinterpret_cast<const float4*>(q1)[1];
+    const float w0 = 1.f - lx;
+    float o[8] = {w0 * a0.x + lx * a1.x, w0 * a0.y + lx * a1.y, w0 * a0.z + lx * a1.z, w0 * a0.w + lx * a1.w,
+                  w0 * b0.x + lx * b1.x, w0 * b0.y + lx * b1.y, w0 * b0.z + lx * b1.z, w0 * b0.w + lx * b1.w};
+    const int zo = 2 * zb + (r >> 1), yo = 2 * yb + (r & 1);
+    store8(out + ((((n * Do + zo) * Ho + yo) * Wo + xo) * (long long)C) + g * 8, o);
+  }
+}
+
 // gather form of the transposed interpolation: one lane per (input voxel, 8 channels)
 template <typename T>
 __global__ void upsample2_bwd_kernel(const T* __restrict__ g_out, int C, T* g_in, int accumulate, int D,
@@ -503,6 +588,21 @@ int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void
 int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims d, hipStream_t s) {
   SEUNET_CHECK(C % 8 == 0, "upsample2: C=%d must be a multiple of 8", C);
   const long long total = (long long)d.N * d.vox() * 8 * (C / 8);
+  const size_t lds = (size_t)4 * UF_XC * C * sizeof(float);
+  if (lds <= 144 * 1024 && (long long)d.N * d.D <= 65535 && d.H <= 65535) {   // up to 128 channels
+    static unsigned long long configured_b = 0, configured_f = 0;
+    if (lds > 48 * 1024) {
+      if (dtype == SEUNET_BF16 && first_use_on_device(configured_b))
+        SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_tiled_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      if (dtype != SEUNET_BF16 && first_use_on_device(configured_f))
+        SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_tiled_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    }
+    dim3 grid((unsigned)((2 * d.W + UF_XF - 1) / UF_XF), (unsigned)d.H, (unsigned)((long long)d.N * d.D));
+    if (dtype == SEUNET_BF16) upsample2_fwd_tiled_kernel<bf16_t><<<grid, 256, lds, s>>>((const bf16_t*)in, C, (bf16_t*)out, d.D, d.H, d.W);
+    else upsample2_fwd_tiled_kernel<float><<<grid, 256, lds, s>>>((const float*)in, C, (float*)out, d.D, d.H, d.W);
+    SEUNET_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == SEUNET_BF16)
     upsample2_fwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, C, (bf16_t*)out, d.D, d.H, d.W, total);
   else

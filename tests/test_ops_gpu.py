@@ -442,3 +442,17 @@ def test_conv_stream_weight_gradient(S, case, shape):
     # and the tiled kernel's answer on the same operands
     ref2 = S.conv3d_wgrad([S.to_cl(x.cuda(), "bf16")], S.to_cl(dy.cuda(), "bf16"), cin, cout, 27, dil)
     assert float((got - ref2).abs().max()) <= 2e-3 * float(wt.grad.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(1, 32, 5, 7, 70), (2, 64, 3, 4, 33), (1, 8, 1, 1, 2), (1, 16, 2, 9, 64), (1, 128, 2, 3, 5)])
+def test_upsample2_forward_backward_shapes(S, dtype, shape):
+    """x2 trilinear (align_corners=True) on the tiled kernels: more than one 128-voxel x-chunk, odd extents, single rows,
+    and the 128-channel case (width x2) that takes the gather kernel."""
+    n, c, d, h, w = shape
+    y = rnd(dtype, gen(n, c, d, h, w, seed=41)).requires_grad_(True)
+    u_ref = F.interpolate(y, scale_factor=2, mode="trilinear", align_corners=True)
+    gu = rnd(dtype, gen(*u_ref.shape, seed=42))
+    u_ref.backward(gu)
+    assert_close(S.from_cl(S.upsample2_fwd(S.to_cl(y.detach().cuda(), dtype))), u_ref, dtype, "upsample")
+    assert_close(S.from_cl(S.upsample2_bwd(S.to_cl(gu.cuda(), dtype))), y.grad, dtype, "upsample bwd")
