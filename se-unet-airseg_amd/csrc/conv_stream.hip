@@ -20,6 +20,7 @@
 //   CIN 32 -> COUT <= 16 : v_mfma_f32_16x16x32 (K = the 32 channels of one tap)                       dc6 fwd, ec3 dgrad
 //   CIN  8 -> COUT <= 16 : v_mfma_f32_16x16x32 with the three x-taps folded into K (3 x 8 channels of the contiguous
 //                          voxels x-1, x, x+1 + 8 zero weights): 9 MFMAs per 16 voxels instead of 27   ec1 fwd, ec2 fwd
+//   CIN 16 -> COUT <= 16 : the same with two x-taps per MFMA (2 x 16 channels): 18 MFMAs per 16 voxels       ec2 dgrad
 // Dilation 2 marches each z-parity class separately (planes z, z+2, ...) and keeps the natural layout in the plane (halo 2).
 // LDS image of a plane: planar [16-B piece of the channels][voxel of the halo patch][16 B]; fragment reads are ds_read_b128
 // of consecutive voxels (conflict-free), DMA instructions write 1 KB contiguous.
@@ -45,7 +46,9 @@ static constexpr int ST_TY = 8, ST_TX = 32, ST_NW = 8;   // 8 waves: one output 
 
 template <int CIN, int COUTP, bool XFOLD, int DIL, bool DACC = false> struct StreamGeo {
   static constexpr int NP = CIN / 8;
-  static constexpr int HX = ST_TX + 2 * DIL + (XFOLD ? 1 : 0), HY = ST_TY + 2 * DIL;
+  static constexpr int VPK = XFOLD ? 32 / CIN : 1;             // x-taps folded into the K = 32 of one 16x16x32 MFMA (CIN 8: 4 slots, CIN 16: 2)
+  static constexpr int NDX = XFOLD ? (3 + VPK - 1) / VPK : 3, NTAP = 9 * NDX;
+  static constexpr int HX = ST_TX + 2 * DIL + (NDX * VPK - 3) * DIL, HY = ST_TY + 2 * DIL;   // (+ the columns the padding slots read)
   static constexpr int NVP = HX * HY, G = (NVP + 63) / 64;
   static constexpr int PS = G * 1024, PLANE = NP * PS;
   static constexpr int OLDI = COUTP == 32 ? 2 : 1;             // DMA instructions per old destination row (32 voxels x <= 32 channels x 2 B <= 2 KB)
@@ -55,7 +58,6 @@ template <int CIN, int COUTP, bool XFOLD, int DIL, bool DACC = false> struct Str
   static constexpr int RING = PF + 2;
   static constexpr int ITEMS = (NP * G + ST_NW - 1) / ST_NW;     // DMA wave-instructions per wave and plane
   static constexpr int NB = COUTP == 32 ? 32 : 16, NBX = ST_TX / NB;
-  static constexpr int NDX = XFOLD ? 1 : 3, NTAP = 9 * NDX;
   static constexpr int STORES = COUTP == 32 ? 4 : NBX;           // store wave-instructions per wave and step
   static constexpr int BIAS = RING * PLANE + 1024;          // f32 bias table (32-channel tiles keep it here instead of 16 registers per lane)
   static constexpr int OLD = BIAS + 256;                       // old destination rows (gradient accumulation): [ring slots][8 waves][OLDI KB]
@@ -171,7 +173,7 @@ conv_stream_kernel(StreamArgs a) {
   const int ra = wave;
   // LDS byte offset of the lane's fragment for input row index ri = 0..2 (y = ra + DIL * (ri - 1)), x-block xbk, tap dx:
   //   ((ra + DIL*ri) * HX + xbk*NB + fn + DIL*(dx+1)) * 16 + piece * PS      (halo origin = -DIL in y and x)
-  const int frag0 = XFOLD ? ((ra * HX + fn + fg) * 16) : ((ra * HX + fn) * 16 + fg * PS);
+  const int frag0 = XFOLD ? ((ra * HX + fn + DIL * (fg / NP)) * 16 + (fg % NP) * PS) : ((ra * HX + fn) * 16 + fg * PS);
 
   AccT acc[3][NBX];
 #pragma unroll
@@ -220,7 +222,7 @@ conv_stream_kernel(StreamArgs a) {
         for (int dxi = 0; dxi < NDX; ++dxi)
 #pragma unroll
           for (int b = 0; b < NBX; ++b) {
-            const int off = frag0 + ((DIL * ri) * HX + b * NB + (XFOLD ? 0 : DIL * dxi)) * 16;
+            const int off = frag0 + ((DIL * ri) * HX + b * NB + DIL * Geo::VPK * dxi) * 16;
             fr[ri & 1][dxi][b] = *reinterpret_cast<const bf16x8*>(pl + off);
           }
       }
@@ -375,14 +377,15 @@ conv_stream_kernel(StreamArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 // weight packing: PyTorch (Cout, Cin, 3, 3, 3) f32 -> [tap][lane][8] MFMA A-operand fragments
 // ------------------------------------------------------------------------------------------------------------------
-struct StreamPackArgs { const float* w; void* out; int cin_w, cout_w, tflip, cin_e, cout_e, coutp, xfold; };
+struct StreamPackArgs { const float* w; void* out; int cin_w, cout_w, tflip, cin_e, cout_e, coutp, xfold, np; };
 
 template <typename T>
 __global__ void __launch_bounds__(64)
 conv_stream_pack_kernel(StreamPackArgs p) {
   // blockIdx.x = packed tap index; one wave writes the 64 fragments of that tap
   const int lane = threadIdx.x;
-  const int ndx = p.xfold ? 1 : 3;
+  const int vpk = p.xfold ? 4 / p.np : 1;       // x-tap slots per MFMA
+  const int ndx = p.xfold ? (3 + vpk - 1) / vpk : 3;
   const int k = blockIdx.x;                   // ((dz*3 + dy) * ndx + dxi)
   const int dxi = k % ndx, zy = k / ndx;
   const int row = p.coutp == 32 ? (lane & 31) : (lane & 15);     // output channel
@@ -390,7 +393,7 @@ conv_stream_pack_kernel(StreamPackArgs p) {
   T* out = reinterpret_cast<T*>(p.out) + ((size_t)k * 64 + lane) * 8;
   for (int j = 0; j < 8; ++j) {
     int ci, dx;
-    if (p.xfold) { ci = j; dx = grp; }        // K = (x-tap grp, channel j); grp 3 = zero padding
+    if (p.xfold) { ci = 8 * (grp % p.np) + j; dx = vpk * dxi + grp / p.np; }   // K = (x-tap slot, channel); slots >= 3: zero padding
     else { ci = 8 * grp + j; dx = dxi; }
     float v = 0.f;
     if (row < p.cout_e && ci < p.cin_e && dx < 3) {
@@ -405,14 +408,15 @@ conv_stream_pack_kernel(StreamPackArgs p) {
 // which variant serves (padded source channels, destination channels); 0 = none
 static int stream_variant(int dtype, int taps, int dil, int src_c, int dst_c) {
   if (dtype != SEUNET_BF16 || taps != 27 || (dil != 1 && dil != 2)) return 0;
-  if (src_c == 8 && dst_c <= 16 && dil == 1) return 3;      // x-folded
+  if (src_c == 8 && dst_c <= 16 && dil == 1) return 3;      // x-folded, 4 slots
+  if (src_c == 16 && dst_c <= 16) return 4;                 // x-folded, 2 slots
   if (src_c == 16 && dst_c <= 32) return 1;
   if (src_c == 32 && dst_c <= 16) return 2;
   return 0;
 }
 bool conv_stream_supported(int dtype, int taps, int dil, int src_c, int dst_c) { return stream_variant(dtype, taps, dil, src_c, dst_c) != 0; }
 
-size_t conv_stream_wpack_bytes(int src_c) { return (size_t)(src_c == 8 ? 9 : 27) * 64 * 16; }
+size_t conv_stream_wpack_bytes(int src_c) { return (size_t)27 * 64 * 16; (void)src_c; }
 
 static int stream_zsteps(int planes) {
   // output planes per workgroup: long marches amortise the 2-plane pipeline fill; 1/3 .. 1/4 of the axis keeps >= 1000
@@ -432,8 +436,8 @@ int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, in
   const int var = stream_variant(dtype, 27, 1, src_c, dst_c);
   SEUNET_CHECK(var != 0 && w && wpack, "conv_stream_pack: unsupported shape (%d -> %d channels)", src_c, dst_c);
   SEUNET_CHECK(cin_e <= src_c && cout_e <= dst_c, "conv_stream_pack: weight (%d -> %d) exceeds the tensors (%d -> %d)", cin_e, cout_e, src_c, dst_c);
-  StreamPackArgs p{w, wpack, cin_w, cout_w, tflip, cin_e, cout_e, var == 1 ? 32 : 16, var == 3 ? 1 : 0};
-  conv_stream_pack_kernel<bf16_t><<<var == 3 ? 9 : 27, 64, 0, s>>>(p);
+  StreamPackArgs p{w, wpack, cin_w, cout_w, tflip, cin_e, cout_e, var == 1 ? 32 : 16, (var == 3 || var == 4) ? 1 : 0, src_c / 8};
+  conv_stream_pack_kernel<bf16_t><<<var == 3 ? 9 : (var == 4 ? 18 : 27), 64, 0, s>>>(p);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -480,6 +484,7 @@ int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const voi
   SEUNET_CHECK(d.N <= 65535 && a.nzseg * dil <= 65535, "conv_stream: grid too large");
   dim3 grid(a.nyb * a.nxb, a.nzseg * dil, d.N);
   if (var == 3) return stream_launch_one<bf16_t, 8, 16, true, 1>(a, grid, s);
+  if (var == 4) return dil == 1 ? stream_launch_one<bf16_t, 16, 16, true, 1>(a, grid, s) : stream_launch_one<bf16_t, 16, 16, true, 2>(a, grid, s);
   if (var == 1) return dil == 1 ? stream_launch_one<bf16_t, 16, 32, false, 1>(a, grid, s) : stream_launch_one<bf16_t, 16, 32, false, 2>(a, grid, s);
   return dil == 1 ? stream_launch_one<bf16_t, 32, 16, false, 1>(a, grid, s) : stream_launch_one<bf16_t, 32, 16, false, 2>(a, grid, s);
 }

@@ -502,6 +502,49 @@ __global__ void up_transpose_axis_kernel(const float* __restrict__ in, float* __
   }
 }
 
+// The x-axis pass of head_bwd for ALL levels of a head in one launch, plus the partial sums of the bias gradient: g_pred (the
+// largest tensor on this path, 4 B per full-resolution voxel) is read once instead of once per level and once more for
+// sum(g_pred).  One wave per x-row; same weights and summation order as up_transpose_axis_kernel (bitwise identical).
+__global__ void __launch_bounds__(256)
+head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, float* __restrict__ t1b, float* __restrict__ t1c,
+                        int nl, int W, long long rows, double* __restrict__ bias_part) {
+  extern __shared__ float hrow[];                       // [4][W]
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + wv;
+  float* rb = hrow + wv * W;
+  double sum = 0.0;
+  if (row < rows)
+    for (int x = lane; x < W; x += 64) { const float v = g[row * W + x]; rb[x] = v; sum += (double)v; }
+  __syncthreads();
+  if (row < rows) {
+    float* const outs[3] = {t1a, t1b, t1c};
+    for (int l = 1; l < nl; ++l) {
+      float* out = outs[l - 1];
+      if (out == nullptr) continue;
+      const int Wl = W >> l;
+      const float rs = ac_scale(Wl, W);
+      for (int i = lane; i < Wl; i += 64) {
+        int lo, hi;
+        ac_range(i, rs, W, lo, hi);
+        float acc = 0.f;
+        for (int o = lo; o <= hi; ++o) {
+          const float w = ac_weight(o, i, rs, Wl);
+          if (w != 0.f) acc += w * rb[o];
+        }
+        out[row * Wl + i] = acc;
+      }
+    }
+  }
+  if (bias_part != nullptr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    __shared__ double wsum[4];
+    if (lane == 0) wsum[wv] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) bias_part[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  }
+}
+
 // deterministic two-stage sum of an f32 array (16-byte loads when the array allows it; f64 accumulation)
 __global__ void __launch_bounds__(256) sum_stage1_kernel(const float* __restrict__ in, long long n,
                                                          double* __restrict__ partial) {
@@ -528,6 +571,22 @@ __global__ void __launch_bounds__(64) sum_stage2_kernel(const double* __restrict
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
   if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+// the same with 1024 threads for long partial arrays (fixed order: thread-strided sums, wave shuffles, 16 waves in order)
+__global__ void __launch_bounds__(1024) sum_stage2_wide_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += partial[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ double w[16];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += w[k];
+    out[0] = (float)t;
+  }
 }
 
 // ---------------- launchers -----------------------------------------------------------------------
@@ -677,33 +736,42 @@ int launch_head_fwd(const float* const* level_maps, int nlevels, const float* bi
   return 0;
 }
 
-size_t head_bwd_tmp_floats(Dims d0) { return (size_t)d0.N * d0.vox() + 2 * 4096; }
+size_t head_bwd_tmp_floats(Dims d0) {
+  // x-pass outputs of the (<= 3) coarse levels (7/8 of a full-resolution map) + one y-pass output (<= 1/4) + bias partials (f64)
+  const size_t v = (size_t)d0.N * d0.vox();
+  return v + v / 4 + 64 + 2 * (((size_t)d0.N * d0.D * d0.H + 3) / 4 + 64);
+}
 
 // g_levels[0] is not written (level 0 uses g_pred itself); g_levels[l>=1] receive the transposed
 // interpolation of g_pred; g_bias (optional) receives sum(g_pred).
 int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, float* tmp, float* g_bias,
                     Dims d0, hipStream_t s) {
   SEUNET_CHECK(nlevels >= 1 && nlevels <= 4, "head: nlevels=%d out of range", nlevels);
-  const long long V0 = d0.vox();
+  const long long rows = (long long)d0.N * d0.D * d0.H;
+  const long long V = rows * d0.W;
+  // workspace: t1[l] = [N][D0][H0][Wl] for l = 1..3, then t2 (one level at a time), then the bias partials
+  float* t1[4] = {nullptr, nullptr, nullptr, nullptr};
+  long long off = 0;
+  for (int l = 1; l < nlevels; ++l) {
+    if (g_levels[l]) t1[l] = tmp + off;
+    off += rows * (d0.W >> l);
+  }
+  float* t2 = tmp + (V - V / 8);                              // (>= the sum of the t1 sizes)
+  double* part = reinterpret_cast<double*>(tmp + ((V + V / 4 + 64 + 1) & ~1ll));
+  const int nblk = (int)((rows + 3) / 4);
+  SEUNET_CHECK(d0.W <= 4096, "head_bwd: W=%d too large", d0.W);
+  head_bwd_x_multi_kernel<<<nblk, 256, (size_t)4 * d0.W * sizeof(float), s>>>(g_pred, t1[1], t1[2], t1[3], nlevels, d0.W, rows,
+                                                                             g_bias ? part : nullptr);
   for (int l = 1; l < nlevels; ++l) {
     if (!g_levels[l]) continue;
     const int Dl = d0.D >> l, Hl = d0.H >> l, Wl = d0.W >> l;
-    float* t1 = tmp;                                        // [N][D0][H0][Wl]
-    float* t2 = tmp + (long long)d0.N * d0.D * d0.H * Wl;   // [N][D0][Hl][Wl]
-    long long tot = (long long)d0.N * d0.D * d0.H * Wl;
-    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(g_pred, t1, Wl, d0.W, 1, tot);
-    tot = (long long)d0.N * d0.D * Hl * Wl;
-    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(t1, t2, Hl, d0.H, Wl, tot);
+    long long tot = (long long)d0.N * d0.D * Hl * Wl;
+    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(t1[l], t2, Hl, d0.H, Wl, tot);
     tot = (long long)d0.N * Dl * Hl * Wl;
     up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(t2, g_levels[l], Dl, d0.D, (long long)Hl * Wl, tot);
-    SEUNET_LAUNCH_CHECK();
   }
-  if (g_bias) {
-    double* part = reinterpret_cast<double*>(tmp + (((size_t)d0.N * V0 + 1) & ~(size_t)1));
-    sum_stage1_kernel<<<1024, 256, 0, s>>>(g_pred, (long long)d0.N * V0, part);
-    sum_stage2_kernel<<<1, 64, 0, s>>>(part, 1024, g_bias);
-    SEUNET_LAUNCH_CHECK();
-  }
+  if (g_bias) sum_stage2_wide_kernel<<<1, 1024, 0, s>>>(part, nblk, g_bias);
+  SEUNET_LAUNCH_CHECK();
   return 0;
 }
 
