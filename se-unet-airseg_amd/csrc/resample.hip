@@ -504,36 +504,62 @@ __global__ void up_transpose_axis_kernel(const float* __restrict__ in, float* __
 
 // The x-axis pass of head_bwd for ALL levels of a head in one launch, plus the partial sums of the bias gradient: g_pred (the
 // largest tensor on this path, 4 B per full-resolution voxel) is read once instead of once per level and once more for
-// sum(g_pred).  One wave per x-row; same weights and summation order as up_transpose_axis_kernel (bitwise identical).
+// sum(g_pred).  The interpolation weights depend on the x index only: each block tabulates them once in LDS (range start
+// + up to HB_K weights per output and level) and then streams HB_ROWS x-rows, one wave per row.  Same weights and the same
+// summation order as up_transpose_axis_kernel (bitwise identical results).
+constexpr int HB_ROWS = 32, HB_K = 24;
 __global__ void __launch_bounds__(256)
 head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, float* __restrict__ t1b, float* __restrict__ t1c,
                         int nl, int W, long long rows, double* __restrict__ bias_part) {
-  extern __shared__ float hrow[];                       // [4][W]
+  extern __shared__ float hsm[];                        // [4][W] row buffers, then per output the table: lo, n, HB_K weights
+  float* tab = hsm + 4 * W;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4ll + wv;
-  float* rb = hrow + wv * W;
-  double sum = 0.0;
-  if (row < rows)
-    for (int x = lane; x < W; x += 64) { const float v = g[row * W + x]; rb[x] = v; sum += (double)v; }
+  float* const outs[3] = {t1a, t1b, t1c};
+  // table: outputs of level l occupy entries [ebase_l, ebase_l + W >> l)
+  int ebase[4] = {0, 0, W >> 1, (W >> 1) + (W >> 2)};
+  const int nent = (nl > 1 ? W >> 1 : 0) + (nl > 2 ? W >> 2 : 0) + (nl > 3 ? W >> 3 : 0);
+  for (int e = threadIdx.x; e < nent; e += 256) {
+    const int l = e < ebase[2] ? 1 : (e < ebase[3] ? 2 : 3);
+    const int i = e - ebase[l], Wl = W >> l;
+    const float rs = ac_scale(Wl, W);
+    int lo, hi;
+    ac_range(i, rs, W, lo, hi);
+    float* t = tab + e * (HB_K + 2);
+    int cnt = 0, first = lo;
+    bool started = false;
+    for (int o = lo; o <= hi; ++o) {
+      const float w = ac_weight(o, i, rs, Wl);
+      if (!started && w == 0.f) { first = o + 1; continue; }     // leading zero weights: skipped exactly like `if (w != 0)`
+      started = true;
+      if (cnt < HB_K) t[2 + cnt] = w;
+      ++cnt;
+    }
+    t[0] = __int_as_float(first);
+    t[1] = __int_as_float(cnt < HB_K ? cnt : HB_K);
+  }
   __syncthreads();
-  if (row < rows) {
-    float* const outs[3] = {t1a, t1b, t1c};
-    for (int l = 1; l < nl; ++l) {
+  double sum = 0.0;
+  const long long row0 = (long long)blockIdx.x * HB_ROWS;
+  for (int rr = wv; rr < HB_ROWS; rr += 4) {
+    const long long row = row0 + rr;
+    if (row >= rows) break;                              // (wave-uniform)
+    float* rb = hsm + wv * W;
+    for (int x = lane; x < W; x += 64) { const float v = g[row * W + x]; rb[x] = v; sum += (double)v; }
+    __builtin_amdgcn_wave_barrier();                     // LDS operations of one wave complete in order
+    for (int e = lane; e < nent; e += 64) {
+      const int l = e < ebase[2] ? 1 : (e < ebase[3] ? 2 : 3);
       float* out = outs[l - 1];
       if (out == nullptr) continue;
-      const int Wl = W >> l;
-      const float rs = ac_scale(Wl, W);
-      for (int i = lane; i < Wl; i += 64) {
-        int lo, hi;
-        ac_range(i, rs, W, lo, hi);
-        float acc = 0.f;
-        for (int o = lo; o <= hi; ++o) {
-          const float w = ac_weight(o, i, rs, Wl);
-          if (w != 0.f) acc += w * rb[o];
-        }
-        out[row * Wl + i] = acc;
+      const float* t = tab + e * (HB_K + 2);
+      const int first = __float_as_int(t[0]), cnt = __float_as_int(t[1]);
+      float acc = 0.f;
+      for (int k = 0; k < cnt; ++k) {
+        const float w = t[2 + k];
+        if (w != 0.f) acc += w * rb[first + k];
       }
+      out[row * (W >> l) + (e - ebase[l])] = acc;
     }
+    __builtin_amdgcn_wave_barrier();
   }
   if (bias_part != nullptr) {
 #pragma unroll
@@ -739,7 +765,7 @@ int launch_head_fwd(const float* const* level_maps, int nlevels, const float* bi
 size_t head_bwd_tmp_floats(Dims d0) {
   // x-pass outputs of the (<= 3) coarse levels (7/8 of a full-resolution map) + one y-pass output (<= 1/4) + bias partials (f64)
   const size_t v = (size_t)d0.N * d0.vox();
-  return v + v / 4 + 64 + 2 * (((size_t)d0.N * d0.D * d0.H + 3) / 4 + 64);
+  return v + v / 4 + 64 + 2 * (((size_t)d0.N * d0.D * d0.H + HB_ROWS - 1) / HB_ROWS + 64);
 }
 
 // g_levels[0] is not written (level 0 uses g_pred itself); g_levels[l>=1] receive the transposed
@@ -758,10 +784,10 @@ int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
   }
   float* t2 = tmp + (V - V / 8);                              // (>= the sum of the t1 sizes)
   double* part = reinterpret_cast<double*>(tmp + ((V + V / 4 + 64 + 1) & ~1ll));
-  const int nblk = (int)((rows + 3) / 4);
-  SEUNET_CHECK(d0.W <= 4096, "head_bwd: W=%d too large", d0.W);
-  head_bwd_x_multi_kernel<<<nblk, 256, (size_t)4 * d0.W * sizeof(float), s>>>(g_pred, t1[1], t1[2], t1[3], nlevels, d0.W, rows,
-                                                                             g_bias ? part : nullptr);
+  const int nblk = (int)((rows + HB_ROWS - 1) / HB_ROWS);
+  SEUNET_CHECK(d0.W <= 1024, "head_bwd: W=%d too large", d0.W);
+  const size_t lds = ((size_t)4 * d0.W + (size_t)(d0.W - (d0.W >> 3)) * (HB_K + 2)) * sizeof(float);
+  head_bwd_x_multi_kernel<<<nblk, 256, lds, s>>>(g_pred, t1[1], t1[2], t1[3], nlevels, d0.W, rows, g_bias ? part : nullptr);
   for (int l = 1; l < nlevels; ++l) {
     if (!g_levels[l]) continue;
     const int Dl = d0.D >> l, Hl = d0.H >> l, Wl = d0.W >> l;
