@@ -9,8 +9,8 @@
  *     local); nothing throws across the ABI, nothing allocates/frees caller memory, nothing
  *     synchronises the device; workspaces are caller-owned;
  *   - re-entrant: no global mutable state, everything is parameterised by (pointers, stream);
- *   - activations inside the library are channels-last [N][D][H][W][C], C a multiple of 8, f32 or
- *     bf16 (SEUNET_F32 / SEUNET_BF16); parameters, logits, losses and gradients of parameters are
+ *   - activations inside the library are channels-last [N][D][H][W][C], C a multiple of 8, f32, bf16 or
+ *     f16 (SEUNET_F32 / SEUNET_BF16 / SEUNET_F16); parameters, logits, losses and gradients of parameters are
  *     f32 in the PyTorch layouts of the reference's state_dict.
  */
 #ifndef SEUNET_HIP_H
@@ -24,6 +24,7 @@ extern "C" {
 #ifndef SEUNET_F32
 #define SEUNET_F32 0
 #define SEUNET_BF16 1
+#define SEUNET_F16 2   /* IEEE half activation storage (BASELINE configs[4] "fp16+MFMA"): v_mfma_*_f16, same rate and bytes as bf16 */
 #endif
 #define SEUNET_CONV_MFMA 0   /* implicit-GEMM matrix-core kernels (default)                  */
 #define SEUNET_CONV_NAIVE 1  /* one-thread-per-output HIP kernels (device-side cross-check)  */
@@ -258,7 +259,7 @@ typedef struct seunet_net_desc {
   int batch, in_channel, n_classes;
   int d, h, w;          /* multiples of 8 */
   int width_mult;       /* 1 = reference widths 8/16/32/64 (SE_UNet.py:108-148) */
-  int dtype;            /* activation storage: SEUNET_F32 | SEUNET_BF16 */
+  int dtype;            /* activation storage: SEUNET_F32 | SEUNET_BF16 | SEUNET_F16 */
   int conv_impl;        /* SEUNET_CONV_MFMA | SEUNET_CONV_NAIVE */
   float negative_slope; /* 0.01 (nn.LeakyReLU default, SE_UNet.py:18) */
   float eps;            /* 1e-5 (nn.InstanceNorm3d default) */

@@ -15,8 +15,13 @@ The whole forward (and the whole backward) is ONE call into the library
 launches are native.  There is no PyTorch or CPU fallback: a CPU tensor or a missing ``.so`` raises.
 
 Extras over the reference, all defaulting to its behaviour: ``width_mult``,
-``negative_slope`` (D1), ``act_dtype`` ('bf16' performance mode / 'fp32' 1e-3-parity mode) and a
+``negative_slope`` (D1), ``act_dtype`` ('bf16' performance mode / 'fp16' / 'fp32' 1e-3-parity mode) and a
 device-agnostic ``DropLayer`` with the reference's CPU-generator RNG order (Q6).
+
+fp16 storage (BASELINE configs[4]) needs what the reference never had: the Dice gradients at initialisation are ~1e-8
+per voxel, below half precision's normal range, so the activation gradients are carried multiplied by a STATIC
+``loss_scale`` (default 65536 for fp16, 1 otherwise; a build-side extension, attribute ``model.loss_scale``): the incoming
+logit gradients are multiplied by it, the parameter gradients divided by it, nothing else changes.
 """
 from __future__ import annotations
 
@@ -165,6 +170,7 @@ class _SEUNetFunction(torch.autograd.Function):
         ctx.desc, ctx.ws, ctx.ws_bytes = desc, ws, ws_bytes
         ctx.plist, ctx.drop = plist, (drop1, drop2)
         ctx.dead = meta["dead"]
+        ctx.loss_scale = float(meta.get("loss_scale", 1.0))
         return pred0, pred1
 
     @staticmethod
@@ -179,13 +185,17 @@ class _SEUNetFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             g0 = torch.zeros(shape, dtype=torch.float32, device=dev) if g0 is None else g0.contiguous().float()
             g1 = torch.zeros(shape, dtype=torch.float32, device=dev) if g1 is None else g1.contiguous().float()
+            if ctx.loss_scale != 1.0:       # fp16 storage: keep the activation gradients inside half precision's range
+                g0, g1 = g0 * ctx.loss_scale, g1 * ctx.loss_scale
             # all live parameter gradients are views of ONE flat buffer (one RCCL all-reduce under data parallelism)
-            _, grads = alloc_flat_grads(ctx.plist, ctx.dead, dev)
+            flat, grads = alloc_flat_grads(ctx.plist, ctx.dead, dev)
             garr = _lib.ptr_array(grads)
             parr = _lib.ptr_array(ctx.plist)
             _lib.check(lib.seunet_net_backward(C.byref(ctx.desc), parr, g0.data_ptr(), g1.data_ptr(),
                                                _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
                                                ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr()), "net_backward")
+            if ctx.loss_scale != 1.0:
+                flat.mul_(1.0 / ctx.loss_scale)
         ctx.ws = None
         return (None, None, None, None) + tuple(grads)
 
@@ -200,6 +210,7 @@ class SE_UNet(nn.Module):
         self.width_mult, self.negative_slope = width_mult, negative_slope
         self.act_dtype = act_dtype or _default_dtype()
         self.conv_impl = _default_conv_impl() if conv_impl is None else conv_impl
+        self.loss_scale = 65536.0 if _lib.dtype_code(self.act_dtype) == _lib.F16 else 1.0
         self.batchnorm, self.bias, self.out_channel2, self.sigmoid_output = False, True, 2, 0
         m = width_mult
         # registration order == reference SE_UNet.py:108-153 (state_dict / parameters() order)
@@ -272,7 +283,7 @@ class SE_UNet(nn.Module):
             d2 = d2.reshape(b, 12).to(x.device, torch.float32).contiguous()
         meta = {"in_channel": self.in_channel, "n_classes": self.n_classes, "width_mult": self.width_mult,
                 "dtype": _lib.dtype_code(self.act_dtype), "conv_impl": self.conv_impl,
-                "negative_slope": float(self.negative_slope), "dead": self._dead}
+                "negative_slope": float(self.negative_slope), "dead": self._dead, "loss_scale": float(self.loss_scale)}
         if not self._registry_checked:
             self._check_registry(make_desc(b, self.in_channel, self.n_classes, x.shape[2], x.shape[3], x.shape[4],
                                            self.width_mult, meta["dtype"], self.conv_impl, self.negative_slope))

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEUNET_LIB") or os.path.join(_HERE, "libseunet_hip.so")   # SEUNET_LIB: diagnostic builds only
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 CONV_MFMA, CONV_NAIVE = 0, 1
 LOSS_NSUMS = 7
 DTI_F64, DTI_F32 = 0, 1
@@ -159,4 +159,6 @@ def dtype_code(name: str) -> int:
         return BF16
     if name in ("fp32", "f32", "float32", "float"):
         return F32
-    raise ValueError(f"unsupported activation dtype {name!r} (fp32 or bf16)")
+    if name in ("fp16", "f16", "float16", "half"):
+        return F16
+    raise ValueError(f"unsupported activation dtype {name!r} (fp32, bf16 or fp16)")

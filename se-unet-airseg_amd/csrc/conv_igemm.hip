@@ -36,6 +36,15 @@
 namespace seunet {
 
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
+// LDS fragments are read as 8 x 16-bit patterns (bf16x8); the matrix instruction is chosen by the storage type
+template <typename T> __device__ __forceinline__ float __attribute__((ext_vector_type(16)))
+mfma32_16bit(bf16x8 a, bf16x8 b, float __attribute__((ext_vector_type(16))) c) {
+  if constexpr (std::is_same<T, f16_t>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,6 +73,7 @@ struct ConvKArgs {
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { static constexpr int KC = 16, KSTEPS = 1; };
+template <> struct Frag<f16_t> { static constexpr int KC = 16, KSTEPS = 1; };
 template <> struct Frag<float> { static constexpr int KC = 8, KSTEPS = 4; };
 
 // cross-lane fetches for f32 and f64 values: DPP (row-local patterns) and ds_swizzle xor 16 (within 32 lanes)
@@ -304,7 +314,7 @@ conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns) {
               if constexpr (sizeof(T) == 2)
-                acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b][ns], af[b][ms], acc[ms][ns], 0, 0, 0);
+                acc[ms][ns] = mfma32_16bit<T>(wf[b][ns], af[b][ms], acc[ms][ns]);
               else
                 acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[b][ns], af[b][ms], acc[ms][ns], 0, 0, 0);
             }
@@ -468,12 +478,12 @@ conv_igemm_kernel(ConvKArgs a) {
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             if (dacc) {
               const u32x2 o = __builtin_amdgcn_raw_buffer_load_b64(rd, off, 0, 0);
-              v[0] += bf16_bits_to_f32(o.x & 0xffffu); v[1] += bf16_bits_to_f32(o.x >> 16);
-              v[2] += bf16_bits_to_f32(o.y & 0xffffu); v[3] += bf16_bits_to_f32(o.y >> 16);
+              v[0] += unpack_lo<T>(o.x); v[1] += unpack_hi<T>(o.x);
+              v[2] += unpack_lo<T>(o.y); v[3] += unpack_hi<T>(o.y);
             }
             u32x2 u;
-            u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-            u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+            u.x = pack2<T>(v[0], v[1]);
+            u.y = pack2<T>(v[2], v[3]);
             __builtin_amdgcn_raw_buffer_store_b64(u, rd, off, 0, 0);
           } else {
             if (dacc) {
@@ -505,8 +515,8 @@ conv_igemm_kernel(ConvKArgs a) {
           if constexpr (sizeof(T) == 2) {
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             u32x2 u;
-            u.x = f32_to_bf16_bits(acc[ms][ns][4 * q]) | (f32_to_bf16_bits(acc[ms][ns][4 * q + 1]) << 16);
-            u.y = f32_to_bf16_bits(acc[ms][ns][4 * q + 2]) | (f32_to_bf16_bits(acc[ms][ns][4 * q + 3]) << 16);
+            u.x = pack2<T>(acc[ms][ns][4 * q], acc[ms][ns][4 * q + 1]);
+            u.y = pack2<T>(acc[ms][ns][4 * q + 2], acc[ms][ns][4 * q + 3]);
             *reinterpret_cast<u32x2*>(sp) = u;
           } else {
             u32x4 u;
@@ -542,9 +552,9 @@ conv_igemm_kernel(ConvKArgs a) {
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float lo = bf16_bits_to_f32(u[e] & 0xffffu) + bf16_bits_to_f32(o[e] & 0xffffu);
-                const float hi = bf16_bits_to_f32(u[e] >> 16) + bf16_bits_to_f32(o[e] >> 16);
-                u[e] = f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+                const float lo = unpack_lo<T>(u[e]) + unpack_lo<T>(o[e]);
+                const float hi = unpack_hi<T>(u[e]) + unpack_hi<T>(o[e]);
+                u[e] = pack2<T>(lo, hi);
               }
             } else {
 #pragma unroll
@@ -637,7 +647,7 @@ __global__ void conv_pack_multi_kernel(PackList l) {
 // 32-column workgroups per CU, 128->64 runs 10 % faster with 64 columns.
 static inline int conv_ncol(int cin_e, int cout_e) { return (cout_e > 32 && cin_e >= 64) ? 64 : 32; }
 unsigned long long* g_conv_debug = nullptr;   // set by seunet_debug_set_buffer (diagnostic builds)
-static inline int conv_kc(int dtype) { return dtype == SEUNET_BF16 ? 16 : 8; }
+static inline int conv_kc(int dtype) { return dtype_size(dtype) == 2 ? 16 : 8; }
 
 size_t conv_wpack_bytes(int dtype, int taps, int cin, int cout) {
   const int ncol = conv_ncol(cin, cout), ntiles = cdiv(cout, ncol), nchunks = cdiv(cin, conv_kc(dtype));
@@ -651,10 +661,7 @@ int launch_conv_pack_weights(int dtype, const float* w, int taps, int cin_w, int
   const int ncol = conv_ncol(cin_e, cout_e), nchunks = cdiv(cin_e, conv_kc(dtype));
   const long long total = (long long)(conv_wpack_bytes(dtype, taps, cin_e, cout_e) / dtype_size(dtype));
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  if (dtype == SEUNET_BF16)
-    conv_pack_kernel<bf16_t><<<grid, 256, 0, s>>>(w, taps, cin_w, cout_w, tflip, (bf16_t*)wpack, cin_e, cout_e, nchunks, ncol, total);
-  else
-    conv_pack_kernel<float><<<grid, 256, 0, s>>>(w, taps, cin_w, cout_w, tflip, (float*)wpack, cin_e, cout_e, nchunks, ncol, total);
+  SEUNET_DTYPE_SWITCH(dtype, conv_pack_kernel<T><<<grid, 256, 0, s>>>(w, taps, cin_w, cout_w, tflip, (T*)wpack, cin_e, cout_e, nchunks, ncol, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -672,8 +679,7 @@ int launch_conv_pack_weights_multi(int dtype, const ConvPackJob* jobs, int n, hi
       e.ncol = conv_ncol(e.cin_e, e.cout_e); e.nchunks = cdiv(e.cin_e, conv_kc(dtype));
       e.total = (long long)(conv_wpack_bytes(dtype, j.taps, e.cin_e, e.cout_e) / dtype_size(dtype));
     }
-    if (dtype == SEUNET_BF16) conv_pack_multi_kernel<bf16_t><<<dim3(64, m), 256, 0, s>>>(l);
-    else conv_pack_multi_kernel<float><<<dim3(64, m), 256, 0, s>>>(l);
+    SEUNET_DTYPE_SWITCH(dtype, conv_pack_multi_kernel<T><<<dim3(64, m), 256, 0, s>>>(l));
   }
   SEUNET_LAUNCH_CHECK();
   return 0;
@@ -762,8 +768,8 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
     SEUNET_CHECK((long long)d.vox() * dst.C[i] * (long long)dtype_size(dtype) < (1LL << 31),
                  "conv: one sample of destination %d is %lld bytes; the MFMA path addresses < 2^31 bytes per sample",
                  i, (long long)d.vox() * dst.C[i] * (long long)dtype_size(dtype));
-  if (dtype == SEUNET_BF16) return launch_t<bf16_t>(taps, dil, ncol / 32, a, grid, s);
-  return launch_t<float>(taps, dil, ncol / 32, a, grid, s);
+  SEUNET_DTYPE_SWITCH(dtype, return (launch_t<T>(taps, dil, ncol / 32, a, grid, s)));
+  return 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -833,10 +839,7 @@ int launch_conv_naive(int dtype, int taps, int dil, const SrcList& src, int cin_
   const long long total = (long long)d.N * d.vox() * a.cout;
   const int grid = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
   const int cin_w = tflip ? a.cout : cin_logical;  // the PyTorch weight's Cin extent
-  if (dtype == SEUNET_BF16)
-    conv_naive_kernel<bf16_t><<<grid, 256, 0, s>>>(a, w, taps, dil, tflip, cin_w, total);
-  else
-    conv_naive_kernel<float><<<grid, 256, 0, s>>>(a, w, taps, dil, tflip, cin_w, total);
+  SEUNET_DTYPE_SWITCH(dtype, conv_naive_kernel<T><<<grid, 256, 0, s>>>(a, w, taps, dil, tflip, cin_w, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

@@ -26,6 +26,7 @@
 // of consecutive voxels (conflict-free), DMA instructions write 1 KB contiguous.
 #include "seunet_common.h"
 #include <utility>
+#include <type_traits>
 
 namespace seunet {
 
@@ -33,6 +34,16 @@ typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+typedef f16_t f16x8s __attribute__((ext_vector_type(8)));
+// fragments are 8 x 16-bit patterns; the matrix instruction follows the storage type (bf16 | f16)
+template <typename T> __device__ __forceinline__ f32x16 st_mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (std::is_same<T, f16_t>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, a), __builtin_bit_cast(f16x8s, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ f32x4 st_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (std::is_same<T, f16_t>::value) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8s, a), __builtin_bit_cast(f16x8s, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 struct StreamArgs {
   const void* src; const void* wpack; const float* bias;
@@ -245,10 +256,8 @@ conv_stream_kernel(StreamArgs a) {
             const int tap = ((dz + 1) * 3 + ri) * NDX + dxi;
 #pragma unroll
             for (int b = 0; b < NBX; ++b) {
-              if constexpr (COUTP == 32)
-                acc[ai][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b], 0, 0, 0);
-              else
-                acc[ai][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b], 0, 0, 0);
+              if constexpr (COUTP == 32) acc[ai][b] = st_mfma32<T>(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b]);
+              else acc[ai][b] = st_mfma16<T>(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b]);
             }
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -294,12 +303,12 @@ conv_stream_kernel(StreamArgs a) {
           if constexpr (DACC) {
             const u32x2s o = *reinterpret_cast<const u32x2s*>(smem + Geo::OLD + (slot * ST_NW + wave) * Geo::OLDI * 1024 +
                                                                ((b * NB + fn) * a.dstC + c0) * (int)sizeof(T));
-            w4[0] += bf16_bits_to_f32(o.x & 0xffffu); w4[1] += bf16_bits_to_f32(o.x >> 16);
-            w4[2] += bf16_bits_to_f32(o.y & 0xffffu); w4[3] += bf16_bits_to_f32(o.y >> 16);
+            w4[0] += unpack_lo<T>(o.x); w4[1] += unpack_hi<T>(o.x);
+            w4[2] += unpack_lo<T>(o.y); w4[3] += unpack_hi<T>(o.y);
           }
           u32x2s u;
-          u.x = f32_to_bf16_bits(w4[0]) | (f32_to_bf16_bits(w4[1]) << 16);
-          u.y = f32_to_bf16_bits(w4[2]) | (f32_to_bf16_bits(w4[3]) << 16);
+          u.x = pack2<T>(w4[0], w4[1]);
+          u.y = pack2<T>(w4[2], w4[3]);
           __builtin_amdgcn_raw_buffer_store_b64(u, rd, off, 0, 0);
         }
 #pragma unroll
@@ -407,7 +416,7 @@ conv_stream_pack_kernel(StreamPackArgs p) {
 
 // which variant serves (padded source channels, destination channels); 0 = none
 static int stream_variant(int dtype, int taps, int dil, int src_c, int dst_c) {
-  if (dtype != SEUNET_BF16 || taps != 27 || (dil != 1 && dil != 2)) return 0;
+  if ((dtype != SEUNET_BF16 && dtype != SEUNET_F16) || taps != 27 || (dil != 1 && dil != 2)) return 0;
   if (src_c == 8 && dst_c <= 16 && dil == 1) return 3;      // x-folded, 4 slots
   if (src_c == 16 && dst_c <= 16) return 4;                 // x-folded, 2 slots
   if (src_c == 16 && dst_c <= 32) return 1;
@@ -437,7 +446,8 @@ int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, in
   SEUNET_CHECK(var != 0 && w && wpack, "conv_stream_pack: unsupported shape (%d -> %d channels)", src_c, dst_c);
   SEUNET_CHECK(cin_e <= src_c && cout_e <= dst_c, "conv_stream_pack: weight (%d -> %d) exceeds the tensors (%d -> %d)", cin_e, cout_e, src_c, dst_c);
   StreamPackArgs p{w, wpack, cin_w, cout_w, tflip, cin_e, cout_e, var == 1 ? 32 : 16, (var == 3 || var == 4) ? 1 : 0, src_c / 8};
-  conv_stream_pack_kernel<bf16_t><<<var == 3 ? 9 : (var == 4 ? 18 : 27), 64, 0, s>>>(p);
+  if (dtype == SEUNET_F16) conv_stream_pack_kernel<f16_t><<<var == 3 ? 9 : (var == 4 ? 18 : 27), 64, 0, s>>>(p);
+  else conv_stream_pack_kernel<bf16_t><<<var == 3 ? 9 : (var == 4 ? 18 : 27), 64, 0, s>>>(p);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -463,6 +473,14 @@ static int stream_launch_one(const StreamArgs& a, dim3 grid, hipStream_t s) {
                 : stream_launch_acc<T, CIN, COUTP, XFOLD, DIL, false, false>(a, grid, s);
 }
 
+template <typename T>
+static int stream_dispatch(int var, int dil, const StreamArgs& a, dim3 grid, hipStream_t s) {
+  if (var == 3) return stream_launch_one<T, 8, 16, true, 1>(a, grid, s);
+  if (var == 4) return dil == 1 ? stream_launch_one<T, 16, 16, true, 1>(a, grid, s) : stream_launch_one<T, 16, 16, true, 2>(a, grid, s);
+  if (var == 1) return dil == 1 ? stream_launch_one<T, 16, 32, false, 1>(a, grid, s) : stream_launch_one<T, 16, 32, false, 2>(a, grid, s);
+  return dil == 1 ? stream_launch_one<T, 32, 16, false, 1>(a, grid, s) : stream_launch_one<T, 32, 16, false, 2>(a, grid, s);
+}
+
 // src: [N][D][H][W][src_c] (src_c = 8 | 16 | 32); dst: [N][D][H][W][dst_c], cout valid output channels written
 // (dst_c % 8 == 0, every channel < dst_c is written: channels >= the weight's Cout are zero + bias 0)
 int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
@@ -483,10 +501,7 @@ int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const voi
   a.nyb = cdiv(d.H, ST_TY); a.nxb = cdiv(d.W, ST_TX);
   SEUNET_CHECK(d.N <= 65535 && a.nzseg * dil <= 65535, "conv_stream: grid too large");
   dim3 grid(a.nyb * a.nxb, a.nzseg * dil, d.N);
-  if (var == 3) return stream_launch_one<bf16_t, 8, 16, true, 1>(a, grid, s);
-  if (var == 4) return dil == 1 ? stream_launch_one<bf16_t, 16, 16, true, 1>(a, grid, s) : stream_launch_one<bf16_t, 16, 16, true, 2>(a, grid, s);
-  if (var == 1) return dil == 1 ? stream_launch_one<bf16_t, 16, 32, false, 1>(a, grid, s) : stream_launch_one<bf16_t, 16, 32, false, 2>(a, grid, s);
-  return dil == 1 ? stream_launch_one<bf16_t, 32, 16, false, 1>(a, grid, s) : stream_launch_one<bf16_t, 32, 16, false, 2>(a, grid, s);
+  return dtype == SEUNET_F16 ? stream_dispatch<f16_t>(var, dil, a, grid, s) : stream_dispatch<bf16_t>(var, dil, a, grid, s);
 }
 
 }  // namespace seunet

@@ -220,7 +220,7 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   // the difference between 2 and 3 waves per SIMD for this latency-bound loop
   // bf16 activations: the thread's <= ~130 voxels are summed in f32 registers and converted once (the tensors keep 8
   // mantissa bits; gate = the bf16-autocast comparison), which frees the 32 KB of LDS slots -> twice the blocks per CU
-  constexpr bool F64ACC = !APPLY && sizeof(T) == 4;
+  constexpr bool F64ACC = !APPLY && sizeof(T) == 4;   // (bf16 / f16 storage: f32 thread sums)
   __shared__ double acc64[F64ACC ? 16 : 1][F64ACC ? EPI_THREADS : 1];
   float fdx[8], fdxx[8];   // f32 staging of the f64 sums, flushed every 8 voxels
   float awse[8], awse2[8], aw20[8], aw21[8], am1[8], am2[8];
@@ -703,10 +703,7 @@ int launch_channel_stats(int dtype, const void* t, int C, double* partial, Dims 
   if (int e = check_c(C)) return e;
   dim3 grid(epi_partials(d), d.N);
   SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16)
-      channel_stats_kernel<bf16_t, LPV><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)t, C, partial, d.vox());
-    else
-      channel_stats_kernel<float, LPV><<<grid, EPI_THREADS, 0, s>>>((const float*)t, C, partial, d.vox());
+    SEUNET_DTYPE_SWITCH(dtype, channel_stats_kernel<T, LPV><<<grid, EPI_THREADS, 0, s>>>((const T*)t, C, partial, d.vox()));
   });
   SEUNET_LAUNCH_CHECK();
   return 0;
@@ -726,13 +723,10 @@ int launch_sse_fwd(int dtype, const void* raw, const float* mean, const float* r
   dim3 grid(epi_partials(d) * 4, d.N);   // nothing is reduced here: enough blocks for full occupancy
   const bool g2 = p.w_se2 != nullptr;
   SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16) {
-      if (g2) sse_fwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, (bf16_t*)e_out, head, d.vox());
-      else sse_fwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, C, p, (bf16_t*)e_out, head, d.vox());
-    } else {
-      if (g2) sse_fwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, (float*)e_out, head, d.vox());
-      else sse_fwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, C, p, (float*)e_out, head, d.vox());
-    }
+    SEUNET_DTYPE_SWITCH(dtype, {
+      if (g2) sse_fwd_kernel<T, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, C, p, (T*)e_out, head, d.vox());
+      else sse_fwd_kernel<T, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, C, p, (T*)e_out, head, d.vox());
+    });
   });
   SEUNET_LAUNCH_CHECK();
   return 0;
@@ -759,12 +753,11 @@ int launch_sse_bwd(int dtype, const void* raw, const float* mean, const float* r
   if (int e = check_c(C)) return e;
   if (m1 == nullptr) {
     SEUNET_CHECK(stat_partial && pgrad_partial, "gate_epilogue_bwd pass A needs the partial buffers");
-    return dtype == SEUNET_BF16 ? sse_bwd_t<bf16_t, false>(raw, mean, rstd, C, p, g, head, nullptr, nullptr, nullptr, stat_partial, pgrad_partial, d, s)
-                                : sse_bwd_t<float, false>(raw, mean, rstd, C, p, g, head, nullptr, nullptr, nullptr, stat_partial, pgrad_partial, d, s);
+    SEUNET_DTYPE_SWITCH(dtype, return (sse_bwd_t<T, false>(raw, mean, rstd, C, p, g, head, nullptr, nullptr, nullptr, stat_partial, pgrad_partial, d, s)));
   }
   SEUNET_CHECK(m2 && draw_out, "gate_epilogue_bwd pass B needs m2 and the output tensor");
-  return dtype == SEUNET_BF16 ? sse_bwd_t<bf16_t, true>(raw, mean, rstd, C, p, g, head, m1, m2, draw_out, nullptr, nullptr, d, s)
-                              : sse_bwd_t<float, true>(raw, mean, rstd, C, p, g, head, m1, m2, draw_out, nullptr, nullptr, d, s);
+  SEUNET_DTYPE_SWITCH(dtype, return (sse_bwd_t<T, true>(raw, mean, rstd, C, p, g, head, m1, m2, draw_out, nullptr, nullptr, d, s)));
+  return 1;
 }
 
 int launch_gate_bwd_finalize(const double* stat_partial, int slots, int C, int N, long long count, float* m1, float* m2,
@@ -812,8 +805,7 @@ int xbranch_moment_slots(Dims d) { return epi_partials(d); }
 
 int launch_xbranch_moments(int dtype, const void* x_in, double* partial, Dims d, hipStream_t s) {
   dim3 grid(xbranch_moment_slots(d), d.N);
-  if (dtype == SEUNET_BF16) input_moments_kernel<bf16_t><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)x_in, partial, d.vox());
-  else input_moments_kernel<float><<<grid, EPI_THREADS, 0, s>>>((const float*)x_in, partial, d.vox());
+  SEUNET_DTYPE_SWITCH(dtype, input_moments_kernel<T><<<grid, EPI_THREADS, 0, s>>>((const T*)x_in, partial, d.vox()));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -833,10 +825,7 @@ int launch_cat_fwd_x(int dtype, const void* raw, const float* mean, const float*
   SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_epilogue_fwd_x: in_channel %d (1 or 2)", in_channel);
   dim3 grid(epi_partials(d) * 4, d.N);
   SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16)
-      cat_fwd_kernel<bf16_t, LPV, true, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, (const bf16_t*)x_in, mean2, rstd2, C, slope, (bf16_t*)out, d.vox(), w2, in_channel);
-    else
-      cat_fwd_kernel<float, LPV, true, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, (const float*)x_in, mean2, rstd2, C, slope, (float*)out, d.vox(), w2, in_channel);
+    SEUNET_DTYPE_SWITCH(dtype, cat_fwd_kernel<T, LPV, true, true><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, (T*)out, d.vox(), w2, in_channel));
   });
   SEUNET_LAUNCH_CHECK();
   return 0;
@@ -855,13 +844,10 @@ int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float*
   else SEUNET_CHECK(m2 && m1b && m2b && dx && xw_partial, "cat_epilogue_bwd_x pass B: missing argument");
   dim3 grid(epi_partials(d) * (apply ? 4 : 1), d.N);
   SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16) {
-      if (apply) cat_bwd_kernel<bf16_t, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (bf16_t*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel);
-      else cat_bwd_kernel<bf16_t, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)g_out, (const bf16_t*)raw, mean, rstd, (const bf16_t*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel);
-    } else {
-      if (apply) cat_bwd_kernel<float, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (float*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel);
-      else cat_bwd_kernel<float, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const float*)g_out, (const float*)raw, mean, rstd, (const float*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel);
-    }
+    SEUNET_DTYPE_SWITCH(dtype, {
+      if (apply) cat_bwd_kernel<T, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (T*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel);
+      else cat_bwd_kernel<T, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel);
+    });
   });
   SEUNET_LAUNCH_CHECK();
   return 0;
@@ -874,13 +860,10 @@ int launch_cat_fwd(int dtype, const void* raw, const float* mean, const float* r
   dim3 grid(epi_partials(d) * 4, d.N);
   const bool two = raw2 != nullptr;
   SEUNET_LPV_SWITCH(C / 8, {
-    if (dtype == SEUNET_BF16) {
-      if (two) cat_fwd_kernel<bf16_t, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, (const bf16_t*)raw2, mean2, rstd2, C, slope, (bf16_t*)out, d.vox());
-      else cat_fwd_kernel<bf16_t, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const bf16_t*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (bf16_t*)out, d.vox());
-    } else {
-      if (two) cat_fwd_kernel<float, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, (const float*)raw2, mean2, rstd2, C, slope, (float*)out, d.vox());
-      else cat_fwd_kernel<float, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const float*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (float*)out, d.vox());
-    }
+    SEUNET_DTYPE_SWITCH(dtype, {
+      if (two) cat_fwd_kernel<T, LPV, true><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, (const T*)raw2, mean2, rstd2, C, slope, (T*)out, d.vox());
+      else cat_fwd_kernel<T, LPV, false><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, nullptr, nullptr, nullptr, C, slope, (T*)out, d.vox());
+    });
   });
   SEUNET_LAUNCH_CHECK();
   return 0;
@@ -908,12 +891,11 @@ int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* m
   if (int e = check_c(C)) return e;
   if (m1 == nullptr) {
     SEUNET_CHECK(stat_partial && (!raw2 || stat_partial2), "cat_epilogue_bwd pass A needs the partial buffers");
-    return dtype == SEUNET_BF16 ? cat_bwd_t<bf16_t, false>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d, s)
-                                : cat_bwd_t<float, false>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d, s);
+    SEUNET_DTYPE_SWITCH(dtype, return (cat_bwd_t<T, false>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d, s)));
   }
   SEUNET_CHECK(m2 && dx && (!raw2 || (m1b && m2b && dx2)), "cat_epilogue_bwd pass B: missing argument");
-  return dtype == SEUNET_BF16 ? cat_bwd_t<bf16_t, true>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, dx, dx2, nullptr, nullptr, d, s)
-                              : cat_bwd_t<float, true>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, dx, dx2, nullptr, nullptr, d, s);
+  SEUNET_DTYPE_SWITCH(dtype, return (cat_bwd_t<T, true>(g_out, raw, mean, rstd, raw2, mean2, rstd2, C, slope, m1, m2, m1b, m2b, dx, dx2, nullptr, nullptr, d, s)));
+  return 1;
 }
 
 }  // namespace seunet

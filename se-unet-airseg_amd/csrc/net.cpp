@@ -159,7 +159,7 @@ struct Plan {
     SEUNET_CHECK(d.d % 8 == 0 && d.h % 8 == 0 && d.w % 8 == 0 && d.d >= 8 && d.h >= 8 && d.w >= 8,
                  "net: spatial extents (%d,%d,%d) must be multiples of 8", d.d, d.h, d.w);
     SEUNET_CHECK(d.width_mult == 1 || d.width_mult == 2, "net: width_mult %d unsupported (1 or 2)", d.width_mult);
-    SEUNET_CHECK(d.dtype == SEUNET_F32 || d.dtype == SEUNET_BF16, "net: dtype %d unsupported", d.dtype);
+    SEUNET_CHECK(dtype_ok(d.dtype), "net: dtype %d unsupported (SEUNET_F32 | SEUNET_BF16 | SEUNET_F16)", d.dtype);
     esz = dtype_size(d.dtype);
     for (int l = 0; l < 4; ++l) dims[l] = Dims{d.batch, d.d >> l, d.h >> l, d.w >> l};
     for (int t = 0; t < T_COUNT; ++t) C[t] = kT[t].cbase == 0 ? 8 : kT[t].cbase * d.width_mult;

@@ -626,10 +626,7 @@ static inline int grid_for(long long total, int block = 256) {
 int launch_pack_cl(int dtype, const float* in, int C, void* out, int Cpad, Dims d, hipStream_t s) {
   SEUNET_CHECK(Cpad % 8 == 0 && Cpad >= C, "pack_cl: padded channel count %d invalid for C=%d", Cpad, C);
   const long long V = d.vox(), total = (long long)d.N * V * (Cpad / 8);
-  if (dtype == SEUNET_BF16)
-    pack_cl_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>(in, C, (bf16_t*)out, Cpad, V, total);
-  else
-    pack_cl_kernel<float><<<grid_for(total), 256, 0, s>>>(in, C, (float*)out, Cpad, V, total);
+  SEUNET_DTYPE_SWITCH(dtype, pack_cl_kernel<T><<<grid_for(total), 256, 0, s>>>(in, C, (T*)out, Cpad, V, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -640,10 +637,7 @@ int launch_pack_input(int dtype, const float* x, int in_channel, void* out, Dims
 int launch_unpack_cl(int dtype, const void* in, int C, float* out, Dims d, hipStream_t s) {
   SEUNET_CHECK(C % 8 == 0, "unpack_cl: C=%d must be a multiple of 8", C);
   const long long V = d.vox(), total = (long long)d.N * V * (C / 8);
-  if (dtype == SEUNET_BF16)
-    unpack_cl_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, C, out, V, total);
-  else
-    unpack_cl_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, C, out, V, total);
+  SEUNET_DTYPE_SWITCH(dtype, unpack_cl_kernel<T><<<grid_for(total), 256, 0, s>>>((const T*)in, C, out, V, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -651,10 +645,7 @@ int launch_unpack_cl(int dtype, const void* in, int C, float* out, Dims d, hipSt
 int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims d, hipStream_t s) {
   SEUNET_CHECK(C % 8 == 0 && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0, "maxpool: bad shape");
   const long long total = (long long)d.N * (d.D / 2) * (d.H / 2) * (d.W / 2) * (C / 8);
-  if (dtype == SEUNET_BF16)
-    maxpool_fwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, C, (bf16_t*)out, d.D, d.H, d.W, total);
-  else
-    maxpool_fwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, C, (float*)out, d.D, d.H, d.W, total);
+  SEUNET_DTYPE_SWITCH(dtype, maxpool_fwd_kernel<T><<<grid_for(total), 256, 0, s>>>((const T*)in, C, (T*)out, d.D, d.H, d.W, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -662,10 +653,7 @@ int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void
                        Dims d, hipStream_t s) {
   SEUNET_CHECK(C % 8 == 0 && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0, "maxpool: bad shape");
   const long long total = (long long)d.N * (d.D / 2) * (d.H / 2) * (d.W / 2) * (C / 8);
-  if (dtype == SEUNET_BF16)
-    maxpool_bwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, (const bf16_t*)g_out, C, (bf16_t*)g_in, accumulate, d.D, d.H, d.W, total);
-  else
-    maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, (const float*)g_out, C, (float*)g_in, accumulate, d.D, d.H, d.W, total);
+  SEUNET_DTYPE_SWITCH(dtype, maxpool_bwd_kernel<T><<<grid_for(total), 256, 0, s>>>((const T*)in, (const T*)g_out, C, (T*)g_in, accumulate, d.D, d.H, d.W, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -675,23 +663,16 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims d, hi
   const long long total = (long long)d.N * d.vox() * 8 * (C / 8);
   const size_t lds = (size_t)4 * UF_XC * C * sizeof(float);
   if (lds <= 144 * 1024 && (long long)d.N * d.D <= 65535 && d.H <= 65535) {   // up to 128 channels
-    static unsigned long long configured_b = 0, configured_f = 0;
-    if (lds > 48 * 1024) {
-      if (dtype == SEUNET_BF16 && first_use_on_device(configured_b))
-        SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_tiled_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      if (dtype != SEUNET_BF16 && first_use_on_device(configured_f))
-        SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_tiled_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-    }
+    static unsigned long long configured[3] = {0, 0, 0};
+    if (lds > 48 * 1024 && dtype >= 0 && dtype < 3 && first_use_on_device(configured[dtype]))
+      SEUNET_DTYPE_SWITCH(dtype, SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_tiled_kernel<T>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)));
     dim3 grid((unsigned)((2 * d.W + UF_XF - 1) / UF_XF), (unsigned)d.H, (unsigned)((long long)d.N * d.D));
-    if (dtype == SEUNET_BF16) upsample2_fwd_tiled_kernel<bf16_t><<<grid, 256, lds, s>>>((const bf16_t*)in, C, (bf16_t*)out, d.D, d.H, d.W);
-    else upsample2_fwd_tiled_kernel<float><<<grid, 256, lds, s>>>((const float*)in, C, (float*)out, d.D, d.H, d.W);
+    SEUNET_DTYPE_SWITCH(dtype, upsample2_fwd_tiled_kernel<T><<<grid, 256, lds, s>>>((const T*)in, C, (T*)out, d.D, d.H, d.W));
     SEUNET_LAUNCH_CHECK();
     return 0;
   }
-  if (dtype == SEUNET_BF16)
-    upsample2_fwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)in, C, (bf16_t*)out, d.D, d.H, d.W, total);
-  else
-    upsample2_fwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)in, C, (float*)out, d.D, d.H, d.W, total);
+  SEUNET_DTYPE_SWITCH(dtype, upsample2_fwd_kernel<T><<<grid_for(total), 256, 0, s>>>((const T*)in, C, (T*)out, d.D, d.H, d.W, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -708,16 +689,12 @@ int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int ac
   // tiled separable kernel: LDS = TY * 44 * C floats <= 45 KB with TY = 4 up to 64 channels, TY = 2 up to 128
   const bool tiled = C <= 128 && (long long)d.N * d.D <= 65535 && d.W >= 2;
   if (tiled) {
-    if (dtype == SEUNET_BF16) { if (C <= 64) upsample2_bwd_tiled<bf16_t, 4>(g_out, C, g_in, accumulate, d, s); else upsample2_bwd_tiled<bf16_t, 2>(g_out, C, g_in, accumulate, d, s); }
-    else { if (C <= 64) upsample2_bwd_tiled<float, 4>(g_out, C, g_in, accumulate, d, s); else upsample2_bwd_tiled<float, 2>(g_out, C, g_in, accumulate, d, s); }
+    SEUNET_DTYPE_SWITCH(dtype, { if (C <= 64) upsample2_bwd_tiled<T, 4>(g_out, C, g_in, accumulate, d, s); else upsample2_bwd_tiled<T, 2>(g_out, C, g_in, accumulate, d, s); });
     SEUNET_LAUNCH_CHECK();
     return 0;
   }
   const long long total = (long long)d.N * d.vox() * (C / 8);
-  if (dtype == SEUNET_BF16)
-    upsample2_bwd_kernel<bf16_t><<<grid_for(total), 256, 0, s>>>((const bf16_t*)g_out, C, (bf16_t*)g_in, accumulate, d.D, d.H, d.W, total);
-  else
-    upsample2_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)g_out, C, (float*)g_in, accumulate, d.D, d.H, d.W, total);
+  SEUNET_DTYPE_SWITCH(dtype, upsample2_bwd_kernel<T><<<grid_for(total), 256, 0, s>>>((const T*)g_out, C, (T*)g_in, accumulate, d.D, d.H, d.W, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

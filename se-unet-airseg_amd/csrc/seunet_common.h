@@ -8,8 +8,10 @@
 
 #define SEUNET_F32 0
 #define SEUNET_BF16 1
+#define SEUNET_F16 2   /* IEEE half storage (BASELINE configs[4]); same MFMA rate and byte size as bf16 */
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 
 namespace seunet {
 
@@ -41,7 +43,15 @@ void prof_mark(const char* tag, hipStream_t s);   // no-op unless seunet_prof_en
                             __FILE__, __LINE__);                                      \
   } while (0)
 
-static inline size_t dtype_size(int dtype) { return dtype == SEUNET_BF16 ? 2 : 4; }
+static inline size_t dtype_size(int dtype) { return (dtype == SEUNET_BF16 || dtype == SEUNET_F16) ? 2 : 4; }
+static inline bool dtype_ok(int dtype) { return dtype == SEUNET_F32 || dtype == SEUNET_BF16 || dtype == SEUNET_F16; }
+// run `...` with T = float | bf16_t | f16_t
+#define SEUNET_DTYPE_SWITCH(DT, ...)                                   \
+  do {                                                                 \
+    if ((DT) == SEUNET_BF16) { typedef bf16_t T; __VA_ARGS__; }        \
+    else if ((DT) == SEUNET_F16) { typedef f16_t T; __VA_ARGS__; }     \
+    else { typedef float T; __VA_ARGS__; }                             \
+  } while (0)
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -77,9 +87,23 @@ __device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
 }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }   // v_cvt_f16_f32: RNE, overflow -> inf
+// two 16-bit elements <-> one dword, for either 16-bit storage type
+template <typename T> __device__ __forceinline__ unsigned int pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned int pack2<bf16_t>(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+template <> __device__ __forceinline__ unsigned int pack2<f16_t>(float lo, float hi) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, (f16_t)lo) | ((unsigned int)__builtin_bit_cast(unsigned short, (f16_t)hi) << 16);
+}
+template <typename T> __device__ __forceinline__ float unpack_lo(unsigned int u);
+template <typename T> __device__ __forceinline__ float unpack_hi(unsigned int u);
+template <> __device__ __forceinline__ float unpack_lo<bf16_t>(unsigned int u) { return bf16_bits_to_f32(u & 0xffffu); }
+template <> __device__ __forceinline__ float unpack_hi<bf16_t>(unsigned int u) { return bf16_bits_to_f32(u >> 16); }
+template <> __device__ __forceinline__ float unpack_lo<f16_t>(unsigned int u) { return (float)__builtin_bit_cast(f16_t, (unsigned short)(u & 0xffffu)); }
+template <> __device__ __forceinline__ float unpack_hi<f16_t>(unsigned int u) { return (float)__builtin_bit_cast(f16_t, (unsigned short)(u >> 16)); }
 
 // 8 consecutive channels <-> 8 floats
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
@@ -93,6 +117,16 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
   v[2] = bf16_bits_to_f32(u.y & 0xffffu); v[3] = bf16_bits_to_f32(u.y >> 16);
   v[4] = bf16_bits_to_f32(u.z & 0xffffu); v[5] = bf16_bits_to_f32(u.z >> 16);
   v[6] = bf16_bits_to_f32(u.w & 0xffffu); v[7] = bf16_bits_to_f32(u.w >> 16);
+}
+__device__ __forceinline__ void load8(const f16_t* p, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  v[0] = unpack_lo<f16_t>(u.x); v[1] = unpack_hi<f16_t>(u.x); v[2] = unpack_lo<f16_t>(u.y); v[3] = unpack_hi<f16_t>(u.y);
+  v[4] = unpack_lo<f16_t>(u.z); v[5] = unpack_hi<f16_t>(u.z); v[6] = unpack_lo<f16_t>(u.w); v[7] = unpack_hi<f16_t>(u.w);
+}
+__device__ __forceinline__ void store8(f16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = pack2<f16_t>(v[0], v[1]); u.y = pack2<f16_t>(v[2], v[3]); u.z = pack2<f16_t>(v[4], v[5]); u.w = pack2<f16_t>(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -112,6 +146,13 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 template <typename T> struct Pack8;
 template <> struct Pack8<bf16_t> { uint4 u; };
 template <> struct Pack8<float> { float4 a, b; };
+template <> struct Pack8<f16_t> { uint4 u; };
+__device__ __forceinline__ void load8p(const f16_t* p, Pack8<f16_t>& k) { k.u = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void unpack8(const Pack8<f16_t>& k, float (&v)[8]) {
+  v[0] = unpack_lo<f16_t>(k.u.x); v[1] = unpack_hi<f16_t>(k.u.x); v[2] = unpack_lo<f16_t>(k.u.y); v[3] = unpack_hi<f16_t>(k.u.y);
+  v[4] = unpack_lo<f16_t>(k.u.z); v[5] = unpack_hi<f16_t>(k.u.z); v[6] = unpack_lo<f16_t>(k.u.w); v[7] = unpack_hi<f16_t>(k.u.w);
+}
+__device__ __forceinline__ void zero8p(Pack8<f16_t>& k) { k.u = make_uint4(0, 0, 0, 0); }
 __device__ __forceinline__ void load8p(const bf16_t* p, Pack8<bf16_t>& k) { k.u = *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void load8p(const float* p, Pack8<float>& k) {
   k.a = reinterpret_cast<const float4*>(p)[0];

@@ -20,6 +20,7 @@
 //               into the PyTorch (Cout,Cin,3,3,3) layout
 #include "seunet_common.h"
 #include <utility>
+#include <type_traits>
 
 namespace seunet {
 
@@ -47,6 +48,7 @@ struct WgArgs {
 // (voxel = 2*lattice + parity), so the halo is one lattice voxel for every dilation.
 template <typename T> struct WgTile;
 template <> struct WgTile<bf16_t> { static constexpr int TZ = 2, TY = 4; };
+template <> struct WgTile<f16_t> { static constexpr int TZ = 2, TY = 4; };
 template <> struct WgTile<float> { static constexpr int TZ = 1, TY = 4; };
 
 __device__ __forceinline__ const void* wg_uniform_ptr(const void* p) {
@@ -290,7 +292,12 @@ wgrad_kernel(WgArgs a) {
           __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of this step's MFMA)
           const bf16x8 afr = __builtin_shufflevector(abuf[ST % 3][0], abuf[ST % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
           const bf16x8 bfr = __builtin_shufflevector(bbuf[rk % 2][0], bbuf[rk % 2][1], 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
+          if constexpr (std::is_same<T, f16_t>::value) {   // (the transposing LDS read is type-agnostic: 16-bit patterns)
+            typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr), __builtin_bit_cast(f16x8, bfr), acc[ti], 0, 0, 0);
+          } else {
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);   // keep the issue order written here
         }(), ...);
       }(std::make_integer_sequence<int, NSTEP>{});
@@ -444,8 +451,8 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   SEUNET_CHECK(a.zero != nullptr, "wgrad: cannot allocate the device zero page");
   a.slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + 256);
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
-  const int tz = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TZ : WgTile<float>::TZ;
-  const int ty = dtype == SEUNET_BF16 ? WgTile<bf16_t>::TY : WgTile<float>::TY;
+  const int tz = dtype_size(dtype) == 2 ? WgTile<bf16_t>::TZ : WgTile<float>::TZ;
+  const int ty = dtype_size(dtype) == 2 ? WgTile<bf16_t>::TY : WgTile<float>::TY;
   const int st = taps == 27 ? dil : 1;
   a.tx = cdiv(cdiv(d.W, st), 32); a.ty = cdiv(cdiv(d.H, st), ty); a.tz = cdiv(cdiv(d.D, st), tz);
   a.co_tiles = cdiv(cout, 32);
@@ -454,15 +461,11 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   const int G = wgrad_groups(taps, combos, a.tx * a.ty * a.tz * st * st * st * d.N);
   dim3 grid(G, combos);
   int e;
-  if (dtype == SEUNET_BF16) {
-    if (taps == 1) e = wgrad_launch_one<bf16_t, 1, 1, 4>(a, grid, s);
-    else if (dil == 1) e = wgrad_launch_one<bf16_t, 27, 1, 4>(a, grid, s);
-    else e = wgrad_launch_one<bf16_t, 27, 2, 4>(a, grid, s);
-  } else {
-    if (taps == 1) e = wgrad_launch_one<float, 1, 1, 4>(a, grid, s);
-    else if (dil == 1) e = wgrad_launch_one<float, 27, 1, 4>(a, grid, s);
-    else e = wgrad_launch_one<float, 27, 2, 4>(a, grid, s);
-  }
+  SEUNET_DTYPE_SWITCH(dtype, {
+    if (taps == 1) e = wgrad_launch_one<T, 1, 1, 4>(a, grid, s);
+    else if (dil == 1) e = wgrad_launch_one<T, 27, 1, 4>(a, grid, s);
+    else e = wgrad_launch_one<T, 27, 2, 4>(a, grid, s);
+  });
   if (e) return e;
   wgrad_reduce_kernel<<<dim3(taps * 1024 / 16, combos), 256, 0, s>>>(a.slab, G, taps, cin_logical, cout,
                                                                             a.co_tiles, dw);
@@ -520,8 +523,7 @@ int launch_wgrad_naive(int dtype, int taps, int dil, const SrcList& x, int cin_l
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const long long total = (long long)cout * cin_logical * taps;
   const int grid = (int)((total + 63) / 64);
-  if (dtype == SEUNET_BF16) wgrad_naive_kernel<bf16_t><<<grid, 64, 0, s>>>(a, taps, dil, dw, total);
-  else wgrad_naive_kernel<float><<<grid, 64, 0, s>>>(a, taps, dil, dw, total);
+  SEUNET_DTYPE_SWITCH(dtype, wgrad_naive_kernel<T><<<grid, 64, 0, s>>>(a, taps, dil, dw, total));
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,7 @@
 //     workgroup writes ONE compact slab [27][ci][co]; a second kernel sums the slabs (f64, fixed order: deterministic).
 #include "seunet_common.h"
 #include <utility>
+#include <type_traits>
 
 namespace seunet {
 
@@ -56,11 +57,10 @@ __device__ __forceinline__ void ws_dma16(const void* gsrc, unsigned lds_dst) {
 }
 template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int CIN, int COUT, int DIL>
+template <typename T, int CIN, int COUT, int DIL>
 __global__ void __launch_bounds__(512, 2)
 wgrad_stream_kernel(WsArgs a) {
   using Geo = WsGeo<CIN, COUT, DIL>;
-  typedef bf16_t T;
   constexpr bool XF = Geo::XF;
   constexpr int NP = Geo::NP, HX = Geo::HX, NVP = Geo::NVP, G = Geo::G, PS = Geo::PS, XPLANE = Geo::XPLANE, YPLANE = Geo::YPLANE;
   constexpr int NDY = Geo::NDY, RX = Geo::RX, RY = Geo::RY, XITEMS = Geo::XITEMS, YITEMS = Geo::YITEMS, LW = Geo::LW;
@@ -198,7 +198,12 @@ wgrad_stream_kernel(WsArgs a) {
         for (int dzi = 0; dzi < 3; ++dzi)
 #pragma unroll
           for (int ob = 0; ob < OB; ++ob)
-            acc[u][dzi][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[dzi][ob], acc[u][dzi][ob], 0, 0, 0);
+            if constexpr (std::is_same<T, f16_t>::value) {   // (the transposing reads are type-agnostic 16-bit patterns)
+              typedef f16_t f16x8w __attribute__((ext_vector_type(8)));
+              acc[u][dzi][ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8w, af), __builtin_bit_cast(f16x8w, bf[dzi][ob]), acc[u][dzi][ob], 0, 0, 0);
+            } else {
+              acc[u][dzi][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[dzi][ob], acc[u][dzi][ob], 0, 0, 0);
+            }
       }
     }
   };
@@ -295,7 +300,7 @@ static bool ws_shape_ok(int cin, int cout, int dil) {
   return (cin == 8 && (cout == 8 || cout == 16)) || (cin == 16 && cout == 32) || (cin == 16 && cout == 16);
 }
 bool wgrad_stream_supported(int dtype, int taps, int dil, int x_c, int dy_c) {
-  return dtype == SEUNET_BF16 && taps == 27 && (dil == 1 || dil == 2) && ws_shape_ok(x_c, dy_c, dil);
+  return (dtype == SEUNET_BF16 || dtype == SEUNET_F16) && taps == 27 && (dil == 1 || dil == 2) && ws_shape_ok(x_c, dy_c, dil);
 }
 static int ws_zsteps(Dims d, int dil) {
   // long marches: few slabs, the pipeline fill amortised; aim at >= 256 workgroups (one per CU)
@@ -315,17 +320,21 @@ size_t wgrad_stream_workspace_bytes(int x_c, int dy_c, int dil, Dims d) {
   return (size_t)ws_slabs(d, dil) * 27 * x_c * dy_c * sizeof(float);
 }
 
-template <int CIN, int COUT, int DIL>
-static int ws_launch(const WsArgs& a, dim3 grid, hipStream_t s) {
+template <typename T, int CIN, int COUT, int DIL>
+static int ws_launch_t(const WsArgs& a, dim3 grid, hipStream_t s) {
   using Geo = WsGeo<CIN, COUT, DIL>;
   static_assert(Geo::LDS <= 160 * 1024, "wgrad_stream: LDS budget");
   static unsigned long long configured = 0;
   if (first_use_on_device(configured))
-    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel<CIN, COUT, DIL>),
+    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel<T, CIN, COUT, DIL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
-  wgrad_stream_kernel<CIN, COUT, DIL><<<grid, WS_NW * 64, Geo::LDS, s>>>(a);
+  wgrad_stream_kernel<T, CIN, COUT, DIL><<<grid, WS_NW * 64, Geo::LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;
+}
+template <int CIN, int COUT, int DIL>
+static int ws_launch(int dtype, const WsArgs& a, dim3 grid, hipStream_t s) {
+  return dtype == SEUNET_F16 ? ws_launch_t<f16_t, CIN, COUT, DIL>(a, grid, s) : ws_launch_t<bf16_t, CIN, COUT, DIL>(a, grid, s);
 }
 
 // x: [N][D][H][W][x_c] (x_c = 8 | 16 | 32, cin_w leading channels carry weights); dy: [N][D][H][W][dy_c];
@@ -347,11 +356,11 @@ int launch_wgrad_stream(int dtype, int dil, const void* x, int x_c, int cin_w, c
   SEUNET_CHECK(d.N <= 65535, "wgrad_stream: batch too large");
   dim3 grid(a.nyb * a.nxb, a.nzseg * dil, d.N);
   int e = 1;
-  if (x_c == 8 && dy_c == 8) e = dil == 1 ? ws_launch<8, 8, 1>(a, grid, s) : ws_launch<8, 8, 2>(a, grid, s);
-  else if (x_c == 8 && dy_c == 16) e = dil == 1 ? ws_launch<8, 16, 1>(a, grid, s) : ws_launch<8, 16, 2>(a, grid, s);
-  else if (x_c == 16 && dy_c == 16) e = dil == 1 ? ws_launch<16, 16, 1>(a, grid, s) : ws_launch<16, 16, 2>(a, grid, s);
-  else if (x_c == 16 && dy_c == 32) e = dil == 1 ? ws_launch<16, 32, 1>(a, grid, s) : ws_launch<16, 32, 2>(a, grid, s);
-  else if (x_c == 32 && dy_c == 16) e = ws_launch<32, 16, 1>(a, grid, s);
+  if (x_c == 8 && dy_c == 8) e = dil == 1 ? ws_launch<8, 8, 1>(dtype, a, grid, s) : ws_launch<8, 8, 2>(dtype, a, grid, s);
+  else if (x_c == 8 && dy_c == 16) e = dil == 1 ? ws_launch<8, 16, 1>(dtype, a, grid, s) : ws_launch<8, 16, 2>(dtype, a, grid, s);
+  else if (x_c == 16 && dy_c == 16) e = dil == 1 ? ws_launch<16, 16, 1>(dtype, a, grid, s) : ws_launch<16, 16, 2>(dtype, a, grid, s);
+  else if (x_c == 16 && dy_c == 32) e = dil == 1 ? ws_launch<16, 32, 1>(dtype, a, grid, s) : ws_launch<16, 32, 2>(dtype, a, grid, s);
+  else if (x_c == 32 && dy_c == 16) e = ws_launch<32, 16, 1>(dtype, a, grid, s);
   if (e) return e;
   const int per = 27 * x_c * dy_c;
   wgrad_stream_reduce_kernel<<<cdiv(per, 16), 256, 0, s>>>(a.slab, grid.x * grid.y * grid.z, per, x_c, dy_c, cin_w, cout_w, dw);

@@ -18,11 +18,11 @@ from ._lib import Dims
 
 
 def _tdtype(code: int):
-    return torch.bfloat16 if code == _lib.BF16 else torch.float32
+    return {_lib.BF16: torch.bfloat16, _lib.F16: torch.float16}.get(code, torch.float32)
 
 
 def _code(t: torch.Tensor) -> int:
-    return _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
+    return {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}.get(t.dtype, _lib.F32)
 
 
 def _dims_cl(t: torch.Tensor) -> Dims:

@@ -458,8 +458,6 @@ def test_config4_shape_160_width2_properties(A, orc, dtype):
     """BASELINE configs[4]: 2x channel width, 160^3 (levels 160/80/40/20), 2-byte activations: size-independent
     properties (finite, deterministic, batch independent, gradients for all 116 live tensors), plus agreement of the two
     2-byte storage modes with each other at the level their mantissas allow."""
-    if dtype == "fp16" and not hasattr(A._lib, "F16"):
-        pytest.skip("fp16 storage mode not built")
     m = A.SE_UNet(2, 1, width_mult=2, act_dtype=dtype)
     m.load_state_dict(orc.deterministic_state_dict(2, 1, 2, seed=0))
     m = m.cuda().eval()
@@ -682,3 +680,59 @@ def test_sliding_window_192x160x128_matches_oracle_and_512_speed(A, orc):
         print(f"512^3 sliding window, 343 windows, batch {batch}: {dt:.3f} s ({512 ** 3 / dt / 1e6:.0f} M output voxels/s)")
     assert torch.isfinite(res[4]).all() and float(res[4].min()) > 0.0 and float(res[4].max()) < 1.0
     assert torch.equal(res[1], res[4])
+
+
+def test_fp16_mode_at_least_as_accurate_as_bf16_mode(A, orc):
+    """fp16 activation storage (BASELINE configs[4], `v_mfma_*_f16`): three more mantissa bits than bf16, so against the float64
+    oracle its logits, loss and large gradient tensors must be no worse than the bf16 mode's (x1.1 + a floor); the static
+    loss scale (65536) keeps the ~1e-8 activation gradients inside half precision's range: no tensor may come back zero,
+    infinite or NaN."""
+    b = orc.synthetic_batch(2, (32, 32, 32), 2, seed=3)
+    o64, l64 = _oracle64(orc, 1, b)
+    with torch.no_grad():
+        p64 = o64(b["image"].double())[1]
+    c = {k: v.cuda() for k, v in b.items()}
+    res = {}
+    for dtype in ("bf16", "fp16"):
+        m = build(A, orc, 2, dtype)
+        ge, gd = m(c["image"])
+        loss = A.fused_stage_loss(1, ge, gd, c["label"])
+        loss.backward()
+        errs = {}
+        for (name, p), (_, r) in zip(m.named_parameters(), o64.named_parameters()):
+            if r.grad is None or r.numel() < 4096:
+                continue
+            assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, name
+            errs[name] = float((p.grad.cpu().double() - r.grad).norm() / r.grad.norm())
+        res[dtype] = (float((gd.detach().cpu().double() - p64).abs().max()), abs(float(loss.detach()) - l64), errs)
+    print("logits err bf16 %.3e fp16 %.3e | loss err bf16 %.2e fp16 %.2e | median grad err bf16 %.3f fp16 %.3f" % (
+        res["bf16"][0], res["fp16"][0], res["bf16"][1], res["fp16"][1],
+        float(np.median(list(res["bf16"][2].values()))), float(np.median(list(res["fp16"][2].values())))))
+    assert res["fp16"][0] <= 1.1 * res["bf16"][0] + 1e-3
+    assert res["fp16"][1] <= 1.1 * res["bf16"][1] + 1e-4
+    worse = [(k, v, res["bf16"][2][k]) for k, v in res["fp16"][2].items() if v > 1.1 * res["bf16"][2][k] + 0.02]
+    assert not worse, worse
+
+
+def test_fp16_mode_trains(A, orc):
+    """30 AdamW steps in fp16 mode track the fp32 mode's loss curve like the bf16 mode does (band 5e-3)."""
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 2, 64, 64, 64, generator=g)
+    label = (img[:, 0:1] > 0.97).float()
+    x, lab = img.cuda(), label.cuda()
+    curves = {}
+    for dtype in ("fp32", "fp16"):
+        m = build(A, orc, 2, dtype)
+        opt = A.AdamW(m.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(30):
+            opt.zero_grad(set_to_none=True)
+            e, d = m(x)
+            loss = A.fused_stage_loss(1, e, d, lab)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        curves[dtype] = np.array(losses)
+    f, h = curves["fp32"], curves["fp16"]
+    print("loss curve fp32:", np.round(f[::5], 4), "fp16:", np.round(h[::5], 4), "max |diff| %.4f" % np.abs(f - h).max())
+    assert np.isfinite(h).all() and h[-1] < h[0] - 0.05 and np.abs(f - h).max() <= 5e-3

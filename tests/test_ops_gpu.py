@@ -21,17 +21,19 @@ def S():
     return ops
 
 
-DT = ["fp32", "bf16"]
+DT = ["fp32", "bf16", "fp16"]
 IMPL = [0, 1]  # MFMA, naive
 
 
 def rnd(dtype, t):
-    return t.to(torch.bfloat16).float() if dtype == "bf16" else t
+    if dtype == "bf16":
+        return t.to(torch.bfloat16).float()
+    return t.to(torch.float16).float() if dtype == "fp16" else t
 
 
 def tol(dtype, ref):
     scale = float(ref.abs().max()) + 1e-12
-    return (2e-5 if dtype == "fp32" else 1.2e-2) * scale
+    return {"fp32": 2e-5, "bf16": 1.2e-2, "fp16": 2e-3}[dtype] * scale
 
 
 def assert_close(got, ref, dtype, what=""):
@@ -91,8 +93,8 @@ def test_conv3x3x3_forward_and_stats(S, dtype, impl, case):
     src_stats = ref if impl == 0 else got.cpu()   # MFMA path takes stats from the f32 accumulators
     rm = src_stats.mean(dim=(2, 3, 4))
     rv = src_stats.var(dim=(2, 3, 4), unbiased=False)
-    np.testing.assert_allclose(mean.cpu().numpy(), rm.numpy(), atol=3e-3 if dtype == "bf16" else 2e-5)
-    np.testing.assert_allclose(rstd.cpu().numpy(), (rv + 1e-5).rsqrt().numpy(), rtol=2e-2 if dtype == "bf16" else 2e-4)
+    np.testing.assert_allclose(mean.cpu().numpy(), rm.numpy(), atol=2e-5 if dtype == "fp32" else 3e-3)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (rv + 1e-5).rsqrt().numpy(), rtol=2e-4 if dtype == "fp32" else 2e-2)
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -140,7 +142,7 @@ def test_conv_data_gradient(S, dtype, impl, case):
     o = 0
     for i, c in enumerate(split):
         want = ref[:, o:o + c] + (prev if i == 0 else 0)
-        assert_close(S.from_cl(dsts[i]), rnd(dtype, want) if dtype == "bf16" else want, dtype, f"dgrad dst{i}")
+        assert_close(S.from_cl(dsts[i]), want if dtype == "fp32" else rnd(dtype, want), dtype, f"dgrad dst{i}")
         o += c
 
 
