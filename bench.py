@@ -294,6 +294,8 @@ def main():
     value = voxels_step * args.steps / dt
     ms_step = 1e3 * dt / args.steps
     ar_ms = [a.elapsed_time(b) for a, b in ar_events]
+    if rank == 0:
+        print("per-step ms: " + " ".join(f"{v:.2f}" for v in per_step_ms), file=sys.stderr)
 
     out = {
         "metric": "voxels/sec SE-UNet fwd+bwd, 128^3 patch", "value": value, "unit": "voxels/s", "n_gpus": world,
@@ -305,7 +307,7 @@ def main():
                    "global_batch": B * world, "patch": S, "parallelism": f"dp{world}", "world_size": world,
                    "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                    "droplayer": "train" if args.train_mode else "eval", "final_loss": float(loss.detach())},
-        "median_ms_per_step": statistics.median(per_step_ms),
+        "median_ms_per_step": statistics.median(per_step_ms), "max_ms_per_step": max(per_step_ms),
     }
     if ar_ms:
         out["config"]["grad_allreduce_ms"] = {"median": statistics.median(ar_ms), "max": max(ar_ms),
