@@ -275,6 +275,18 @@ size_t seunet_net_workspace_bytes(const seunet_net_desc* desc);
 int seunet_net_forward(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
                        const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
                        seunet_stream_t s);
+/* The same forward pass recorded as a HIP graph on exactly these pointers (stream capture on `s`, which must not be the
+ * null stream; nothing executes during the capture).  seunet_graph_launch replays it on any stream of the device: the
+ * graph reads params / x / drop1 / drop2 and writes pred0 / pred1 / workspace at replay time, so the caller refreshes
+ * the CONTENTS of those buffers between replays and keeps the buffers themselves alive and in place.  For the
+ * whole-volume inference loop (prediction.py:78-109: the same network call per window, hundreds of times): one graph
+ * launch instead of ~150 kernel launches.  Run the eager seunet_net_forward once on the device first (per-kernel
+ * one-time attribute setup is not stream work).  seunet_graph_destroy(NULL) is a no-op. */
+int seunet_net_forward_capture(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
+                               const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
+                               seunet_stream_t s, void** graph_out);
+int seunet_graph_launch(void* graph, seunet_stream_t s);
+int seunet_graph_destroy(void* graph);
 /* grads: device pointers in registry order, each overwritten (NULL = skip).  The dead block dc62
  * (SE_UNet.py:148,230) receives no gradient: its entry is never written. */
 int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,

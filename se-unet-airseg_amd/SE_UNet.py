@@ -290,6 +290,87 @@ class SE_UNet(nn.Module):
         return _SEUNetFunction.apply(x, d1, d2, meta, *self.parameters())
 
 
+class CapturedForward:
+    """The inference forward of ``model`` on FIXED buffers, recorded once as a HIP graph (``seunet_net_forward_capture``)
+    and replayed per call: what the whole-volume window loops use (prediction.py:78-109 calls the network 343 times on a
+    512^3 case).  Fill ``self.x`` (B, in_channel, D, H, W) -- and, under ``model.train()``, nothing else: ``__call__``
+    draws the DropLayer scales like ``SE_UNet.forward`` -- then call; the logits land in ``self.pred0`` / ``self.pred1``
+    (overwritten by the next call).  No autograd: the workspace is reused, so there is no backward of a replay.
+
+    The graph holds raw pointers: the buffers live in this object, the parameters in the model.  In-place updates of the
+    weights (``optimizer.step()``, ``load_state_dict``) are seen by the next replay; if a parameter tensor is REPLACED
+    (``model.half()``, ``.to()``), the next call notices the changed pointers and records the graph again."""
+
+    def __init__(self, model: "SE_UNet", batch: int, spatial: Tuple[int, int, int]):
+        lib = _lib.load()
+        self.model = model
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("CapturedForward needs the model on an MI355X device (no CPU fallback)")
+        self.device = dev
+        d, h, w = spatial
+        self.desc = make_desc(batch, model.in_channel, model.n_classes, d, h, w, model.width_mult,
+                              _lib.dtype_code(model.act_dtype), model.conv_impl, model.negative_slope)
+        model._check_registry(self.desc)
+        with torch.cuda.device(dev):
+            self.ws_bytes = lib.seunet_net_workspace_bytes(C.byref(self.desc))
+            if self.ws_bytes == 0:
+                raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
+            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+            self.x = torch.zeros((batch, model.in_channel, d, h, w), dtype=torch.float32, device=dev)
+            self.pred0 = torch.empty((batch, 1, d, h, w), dtype=torch.float32, device=dev)
+            self.pred1 = torch.empty_like(self.pred0)
+            self.drop1 = torch.ones((batch, 24), dtype=torch.float32, device=dev)
+            self.drop2 = torch.ones((batch, 12), dtype=torch.float32, device=dev)
+            self._stream = torch.cuda.Stream(device=dev)
+        self._graphs = {}           # training flag -> (handle, parameter pointers, kept-alive tensors)
+
+    def _record(self, training: bool):
+        lib = _lib.load()
+        plist = [p.detach().contiguous() for p in self.model.parameters()]
+        parr = _lib.ptr_array(plist)
+        d1 = self.drop1.data_ptr() if training else None
+        d2 = self.drop2.data_ptr() if training else None
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            args = (C.byref(self.desc), parr, self.x.data_ptr(), d1, d2, self.pred0.data_ptr(), self.pred1.data_ptr(),
+                    self.ws.data_ptr(), self.ws_bytes, _lib.stream_ptr())
+            _lib.check(lib.seunet_net_forward(*args), "net_forward")        # eager once: per-kernel one-time setup
+            self._stream.synchronize()
+            handle = C.c_void_p()
+            _lib.check(lib.seunet_net_forward_capture(*args, C.byref(handle)), "net_forward_capture")
+        cur.wait_stream(self._stream)
+        old = self._graphs.get(training)
+        if old is not None:
+            lib.seunet_graph_destroy(old[0])
+        self._graphs[training] = (handle, [p.data_ptr() for p in plist], plist)
+
+    def __call__(self):
+        lib = _lib.load()
+        training = bool(self.model.training)
+        with torch.cuda.device(self.device):
+            if training:            # RNG order: dropout1 then dropout2 (SE_UNet.py:232-233)
+                b = self.x.shape[0]
+                d1, d2 = self.model.dropout1.scale(b), self.model.dropout2.scale(b)
+                self.drop1.copy_(d1.reshape(b, 24), non_blocking=False)
+                self.drop2.copy_(d2.reshape(b, 12), non_blocking=False)
+            g = self._graphs.get(training)
+            if g is None or g[1] != [p.data_ptr() for p in self.model.parameters()]:
+                self._record(training)
+                g = self._graphs[training]
+            _lib.check(lib.seunet_graph_launch(g[0], _lib.stream_ptr()), "graph_launch")
+        return self.pred0, self.pred1
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            for g in self._graphs.values():
+                lib.seunet_graph_destroy(g[0])
+        except Exception:
+            pass
+
+
 def get_model():
     """reference SE_UNet.py:240-242."""
     net = SE_UNet(in_channel=2)

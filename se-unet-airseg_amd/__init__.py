@@ -6,7 +6,7 @@ Python identifier; import it as ``seunet_amd`` (alias module at the repo root) o
 ``importlib.import_module("se-unet-airseg_amd")``.
 """
 from . import _lib, ddp, ops, optim, pipeline, postprocess
-from .SE_UNet import CATConv, DropLayer, SE_UNet, SSEConv, SSEConv2, get_model
+from .SE_UNet import CapturedForward, CATConv, DropLayer, SE_UNet, SSEConv, SSEConv2, get_model
 from .optim import AdamW
 from .pipeline import CropSegDataGPU, aug_code, crop_batch, draw_stage1_plan, two_channel_volume
 from .postprocess import (MetricSums, double_threshold_iteration, evaluation_case, largest_component, maximum_3d,

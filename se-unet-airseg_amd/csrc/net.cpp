@@ -615,6 +615,59 @@ int seunet_net_forward(const seunet_net_desc* desc, const float* const* params, 
   return ex.forward(x, drop1, drop2, pred0, pred1);
 }
 
+// ---- the forward pass as a HIP graph (inference loops call the same forward on the same buffers hundreds of times:
+// one graph launch replaces ~150 kernel launches, and the dependent-launch gaps between the small kernels of the coarse
+// levels shrink) ----------------------------------------------------------------------------------------------------
+struct NetGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+int seunet_net_forward_capture(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
+                               const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
+                               seunet_stream_t s, void** graph_out) {
+  SEUNET_CHECK(x && pred0 && pred1 && graph_out, "net_forward_capture: null argument");
+  SEUNET_CHECK(s != nullptr, "net_forward_capture: stream capture needs a stream other than the null stream");
+  SEUNET_CHECK(!prof_on(), "net_forward_capture: switch the launch-group timer off before capturing");
+  *graph_out = nullptr;
+  Exec ex;
+  if (int e = ex.setup(desc, params, workspace, workspace_bytes, (hipStream_t)s)) return e;
+  SEUNET_CHECK(device_zero_page() != nullptr, "net_forward_capture: zero page allocation failed");   // (not inside the capture)
+  SEUNET_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+  const int rc = ex.forward(x, drop1, drop2, pred0, pred1);
+  NetGraph* g = new NetGraph;
+  const hipError_t e_end = hipStreamEndCapture((hipStream_t)s, &g->graph);
+  if (rc != 0 || e_end != hipSuccess) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    if (rc != 0) return rc;    // (the message of the failing launch is already recorded)
+    return fail("net_forward_capture: hipStreamEndCapture failed: %s", hipGetErrorString(e_end));
+  }
+  const hipError_t e_inst = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e_inst != hipSuccess) {
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return fail("net_forward_capture: hipGraphInstantiate failed: %s", hipGetErrorString(e_inst));
+  }
+  *graph_out = g;
+  return 0;
+}
+
+int seunet_graph_launch(void* graph, seunet_stream_t s) {
+  SEUNET_CHECK(graph != nullptr, "graph_launch: null graph");
+  SEUNET_HIP(hipGraphLaunch(static_cast<NetGraph*>(graph)->exec, (hipStream_t)s));
+  return 0;
+}
+
+int seunet_graph_destroy(void* graph) {
+  if (!graph) return 0;
+  NetGraph* g = static_cast<NetGraph*>(graph);
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
 int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
                         const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
                         void* workspace, size_t workspace_bytes, seunet_stream_t s) {

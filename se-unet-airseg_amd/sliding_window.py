@@ -42,7 +42,7 @@ def window_table(shape: Sequence[int], cube: int = 128, step: int = 64, pad_to_b
     return pos
 
 
-def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_dup: int) -> torch.Tensor:
+def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_dup: int, graph: bool = False) -> torch.Tensor:
     if not x.is_cuda:
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
     if x.dim() != 5 or x.shape[0] != 1:
@@ -54,14 +54,21 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
     with torch.cuda.device(x.device):
         st = _lib.stream_ptr()
         acc = torch.zeros((X, Y, Z), dtype=torch.float64, device=x.device)
+        # full batches replay ONE recorded HIP graph of the forward pass on fixed buffers; a ragged last batch (another
+        # descriptor) runs eagerly
+        cap = None
+        if graph and len(pos) >= 2 * batch:
+            from .SE_UNet import CapturedForward
+            cap = CapturedForward(model, batch, (cube, cube, cube))
         for i in range(0, len(pos), batch):
             chunk = pos[i:i + batch]
-            xin = torch.empty((len(chunk), C_, cube, cube, cube), dtype=torch.float32, device=x.device)
+            use_cap = cap is not None and len(chunk) == batch
+            xin = cap.x if use_cap else torch.empty((len(chunk), C_, cube, cube, cube), dtype=torch.float32, device=x.device)
             for j in range(0, len(chunk), max_call):
                 sub = chunk[j:j + max_call]
                 arr = _lib.int_array([v for p in sub for v in p])
                 _lib.check(lib.seunet_window_gather(x.data_ptr(), C_, X, Y, Z, cube, len(sub), arr, xin[j:].data_ptr(), st), "window_gather")
-            _, p = model(xin)                           # logits of the decoder head (prediction.py:103 `p0, p = model(...)`)
+            _, p = cap() if use_cap else model(xin)     # logits of the decoder head (prediction.py:103 `p0, p = model(...)`)
             p = p.contiguous()
             for j in range(0, len(chunk), max_call):
                 sub = chunk[j:j + max_call]
@@ -77,19 +84,22 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
 
 @torch.no_grad()
 def sliding_window_predict(model, x: torch.Tensor, cube: int = 128, step: int = 64, batch: int = 1,
-                           return_tensor: bool = False):
+                           return_tensor: bool = False, graph: bool = False):
     """prediction.py:78-109.  x: (1, C, X, Y, Z) on the GPU.  Returns the overlap-averaged sigmoid(pred1) volume as
     float64 numpy (like the reference's host accumulators), or the float64 CUDA tensor with ``return_tensor=True`` (what
     ``double_threshold_iteration`` takes next, prediction.py:110).  ``batch`` windows go through the network per call
-    (the reference uses 1; results are identical in eval mode because InstanceNorm is per sample)."""
+    (the reference uses 1; results are identical in eval mode because InstanceNorm is per sample).  ``graph``: replay the
+    forward pass as one recorded HIP graph per batch (``CapturedForward``: same kernels, same bits).  Off by default: on
+    MI355X the loop is bound by the kernels, not by their launches (512^3: 0.499 s replayed vs 0.493 s launched one by
+    one at batch 4, 0.656 vs 0.648 s at batch 1); it pays only when the host thread is slow or busy."""
     pos = window_table(x.shape[2:], cube, step)
-    out = _assemble(model, x, pos, cube, step, batch, 0)
+    out = _assemble(model, x, pos, cube, step, batch, 0, graph)
     return out if return_tensor else out.cpu().numpy()
 
 
 @torch.no_grad()
 def sliding_window_validate(model, x: torch.Tensor, batch: int = 24, cube: int = 128, step: int = 64,
-                            return_tensor: bool = False):
+                            return_tensor: bool = False, graph: bool = False):
     """The validation / test form of the loop (train.py:682-693 with ``SegValCropData``, data.py:731-773; test.py:151-161
     with batch 8): the window list is padded with copies of window 0 to a multiple of ``batch`` and the copies are run and
     accumulated like any other window.  The reference runs this loop under ``model.train()`` (train.py:632):
@@ -97,5 +107,5 @@ def sliding_window_validate(model, x: torch.Tensor, batch: int = 24, cube: int =
     ``model.train()`` / ``model.eval()`` yourself, as the reference does."""
     pos = window_table(x.shape[2:], cube, step, pad_to_batch=batch)
     n_real = len(window_table(x.shape[2:], cube, step))
-    out = _assemble(model, x, pos, cube, step, batch, len(pos) - n_real)
+    out = _assemble(model, x, pos, cube, step, batch, len(pos) - n_real, graph)
     return out if return_tensor else out.cpu().numpy()

@@ -673,13 +673,49 @@ def test_sliding_window_192x160x128_matches_oracle_and_512_speed(A, orc):
     vol = torch.rand((1, 2, 512, 512, 512), generator=g, device="cuda")
     A.sliding_window_predict(mb, vol[:, :, :128, :128, :256], batch=1, return_tensor=True)      # warm-up
     res = {}
-    for batch in (4, 1):
+    for batch, graph in ((4, True), (1, True), (4, False), (1, False)):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        res[batch] = A.sliding_window_predict(mb, vol, batch=batch, return_tensor=True)
+        res[batch, graph] = A.sliding_window_predict(mb, vol, batch=batch, return_tensor=True, graph=graph)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"512^3 sliding window, 343 windows, batch {batch}: {dt:.3f} s ({512 ** 3 / dt / 1e6:.0f} M output voxels/s)")
-    assert torch.isfinite(res[4]).all() and float(res[4].min()) > 0.0 and float(res[4].max()) < 1.0
-    assert torch.equal(res[1], res[4])
+        print(f"512^3 sliding window, 343 windows, batch {batch}, {'one HIP graph per batch' if graph else 'eager launches'}: "
+              f"{dt:.3f} s ({512 ** 3 / dt / 1e6:.0f} M output voxels/s)")
+    assert torch.isfinite(res[4, True]).all() and float(res[4, True].min()) > 0.0 and float(res[4, True].max()) < 1.0
+    for k in res:
+        assert torch.equal(res[k], res[4, True]), k
+
+
+def test_captured_forward_replays_match_eager_and_follow_weight_updates(A, orc):
+    """CapturedForward (seunet_net_forward_capture): replays of the recorded graph give the eager forward's bits, see
+    in-place weight updates, draw DropLayer scales like the eager path under model.train(), and re-record when a
+    parameter tensor is replaced."""
+    m = build(A, orc, 2, "bf16")
+    x1 = orc.synthetic_batch(2, (64, 64, 64), 2, seed=31)["image"].cuda()
+    x2 = orc.synthetic_batch(2, (64, 64, 64), 2, seed=32)["image"].cuda()
+    cap = A.CapturedForward(m, 2, (64, 64, 64))
+    with torch.no_grad():
+        for x in (x1, x2, x1):
+            cap.x.copy_(x)
+            p0, p1 = cap()
+            e0, e1 = m(x)
+            assert torch.equal(p0, e0) and torch.equal(p1, e1)
+        for p in m.parameters():            # in-place update: same pointers, new values
+            p.mul_(1.01)
+        cap.x.copy_(x2)
+        p0, p1 = cap()
+        e0, e1 = m(x2)
+        assert torch.equal(p0, e0) and torch.equal(p1, e1)
+        m.train()                           # DropLayer active: same CPU-generator draws as the eager call
+        torch.manual_seed(5)
+        p0, p1 = cap()
+        p0, p1 = p0.clone(), p1.clone()
+        torch.manual_seed(5)
+        e0, e1 = m(x2)
+        assert torch.equal(p0, e0) and torch.equal(p1, e1)
+        m.eval()
+        m.dc6.conv1.weight.data = m.dc6.conv1.weight.data.clone() * 0.5     # REPLACED tensor: new pointer
+        p0, p1 = cap()
+        e0, e1 = m(x2)
+        assert torch.equal(p0, e0) and torch.equal(p1, e1)
 
 
 def test_fp16_mode_at_least_as_accurate_as_bf16_mode(A, orc):
