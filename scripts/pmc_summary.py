@@ -10,10 +10,20 @@ def load(sub):
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             key = (r["Kernel_Name"][:90], int(r["Grid_Size"]), int(r["Workgroup_Size"]))
-            rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rows[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     return rows
 fetch, write, sq = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_SQ_VALU_MFMA_BUSY_CYCLES")
-avg = lambda v: sum(v) / max(len(v), 1)
+STEPS = 4        # the profiled command runs --warmup 1 --steps 3
+def avg(v):
+    v = [x[1] if isinstance(x, tuple) else x for x in v]
+    return sum(v) / max(len(v), 1)
+def first_of_each_step(v):
+    """Layers that share a template instantiation AND a grid (the 27-tap weight-gradient kernel runs every layer on the
+    same persistent grid) are told apart by launch order: the dispatches of one key repeat with the step, and dc5's weight
+    gradient is the first of them in every backward pass (dc6 runs on the streaming kernel)."""
+    v = sorted(v)
+    per = max(len(v) // STEPS, 1)
+    return [x for i, x in enumerate(v) if i % per == 0]
 print("%-90s %10s %5s %12s %12s %12s" % ("kernel", "workitems", "n", "fetch MB x2", "write MB", "HBM MB"))
 table = {}
 for key in sorted(set(fetch) | set(write), key=lambda k: -(avg(fetch[k].get("FETCH_SIZE", [0])))):
@@ -29,13 +39,26 @@ for key, c in sorted(sq.items(), key=lambda kv: -avg(kv[1].get("SQ_VALU_MFMA_BUS
     wv, wt = avg(c.get("SQ_WAVE_CYCLES", [0])), avg(c.get("SQ_WAIT_ANY", [0]))
     if m > 0:
         print("%-90s %10d %12.3e %12.3e %10.3f %10.3f" % (key[0], key[1], m, b, m / b if b else 0, wt / wv if wv else 0))
-# the dc5 launch groups at the bench shape (4 x 128^3): tiled conv kernel, 27 taps, dilation 1, 32-column tiles
+# the dc5 launch groups at the bench shape (4 x 128^3): tiled conv kernel, 27 taps (", 27, 1>" / "Li27ELi1E" in the name),
+# forward = 4096 tiles x 1 column block x 4 samples, data gradient = 2 column blocks; 256 threads per workgroup
+def is27(name):
+    n = name.replace(" ", "")
+    return ",27,1>" in n or "Li27ELi1E" in n
 groups = {}
 for key, (f, w) in table.items():
     name, items, wg = key
-    if "conv_igemm_kernel" in name and items == 4096 * 2 * 4 * 256: groups["dgrad:dc5"] = (f, w)
-    if "conv_igemm_kernel" in name and items == 4096 * 1 * 4 * 256 and "Li27" in name.replace(" ", "") or ("conv_igemm_kernel" in name and items == 4096 * 4 * 256 and ", 27, 1" in name): groups.setdefault("conv_fwd:dc5", (f, w))
-    if "wgrad_kernel" in name and "stream" not in name and items == 256 * 2 * 256: groups["wgrad:dc5"] = (f, w)
+    if "conv_igemm_kernel" in name and is27(name) and items == 4096 * 2 * 4 * 256: groups["dgrad:dc5"] = (f, w)
+    if "conv_igemm_kernel" in name and is27(name) and items == 4096 * 1 * 4 * 256: groups["conv_fwd:dc5"] = (f, w)
+for key in fetch:
+    name, items, wg = key
+    if "wgrad_kernel" in name and "stream" not in name and ("Li27ELi1E" in name or ", 27, 1" in name) and items == 256 * 2 * 256:
+        f = avg(first_of_each_step(fetch[key].get("FETCH_SIZE", []))) * 1024 * 2
+        w = avg(first_of_each_step(write[key].get("WRITE_SIZE", []))) * 1024
+        groups["wgrad:dc5"] = (f, w)
+        c = sq.get(key, {})
+        m, b = avg(first_of_each_step(c.get("SQ_VALU_MFMA_BUSY_CYCLES", []))), avg(first_of_each_step(c.get("SQ_BUSY_CU_CYCLES", [])))
+        if b:
+            print("%-90s %10s %12.3e %12.3e %10.3f   (first launch of each step = wgrad:dc5)" % (key[0], "dc5", m, b, m / b))
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py --steps 3 --warmup 1`; "
                    "bytes per launch, FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section)",
            "kernels": {k: {"fetch_bytes": v[0], "write_bytes": v[1], "hbm_bytes_per_launch": v[0] + v[1]} for k, v in groups.items()}},

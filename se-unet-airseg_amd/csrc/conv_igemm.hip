@@ -68,6 +68,7 @@ struct ConvKArgs {
   int nchunks;
   int pair;                  // 1: both 16-B pieces of every channel chunk come from one source tensor (lane-pair staging)
   int direct;                // 1: every destination has <= 16 channels (stores straight from the accumulators)
+  int ncb;                   // column blocks per tile (gridDim.x = tiles * ncb, column block fastest)
   unsigned long long* debug;   // diagnostic builds only (-DSEUNET_STAMP): per-phase cycle sums
 };
 
@@ -123,12 +124,17 @@ conv_igemm_kernel(ConvKArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
-  // XCD-aware order: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous run of tiles
+  // XCD-aware order: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous run of (tile, column block) pairs
+  // with the column block fastest, so the workgroups that read the SAME input tile (one per 32/64-column block of the
+  // outputs) run back to back on one XCD and the second finds the tile in that XCD's L2
   int t;
   {
     const int nt = gridDim.x, b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  const int ntile = t % a.ncb;
+  t /= a.ncb;
+  const int tiles_per_sample = gridDim.x / a.ncb;
   const int tile_slot = t;
   const int bx = t % a.tx; t /= a.tx;
   const int by = t % a.ty; t /= a.ty;
@@ -136,7 +142,7 @@ conv_igemm_kernel(ConvKArgs a) {
   const int par = t / a.tz;                                  // parity class 0..STEP^3-1
   const int px = par % STEP, py = (par / STEP) % STEP, pz = par / (STEP * STEP);
   const int x0 = bx * CV_TX, y0 = by * CV_TY, z0 = bz * CV_TZ;   // lattice coordinates
-  const int ntile = blockIdx.y, n = blockIdx.z;
+  const int n = blockIdx.z;
   const long long V = (long long)a.D * a.H * a.W;
 
   // ---- per-thread staging plan (chunk independent) ----
@@ -578,7 +584,7 @@ conv_igemm_kernel(ConvKArgs a) {
       if (co < a.cout) {
         const double tot = ((red[(0 * NCOL + c) * 2 + k] + red[(1 * NCOL + c) * 2 + k]) +
                             red[(2 * NCOL + c) * 2 + k]) + red[(3 * NCOL + c) * 2 + k];
-        a.stats[(((long long)n * gridDim.x + tile_slot) * a.cout + co) * 2 + k] = tot;
+        a.stats[(((long long)n * tiles_per_sample + tile_slot) * a.cout + co) * 2 + k] = tot;
       }
     }
   }
@@ -757,7 +763,8 @@ int launch_conv_igemm(int dtype, int taps, int dil, const SrcList& src, int cin_
   for (int i = 0; i < dst.n; ++i) if (dst.C[i] * st > 16) a.direct = 0;
   a.debug = g_conv_debug;
   const int ncol = conv_ncol(a.cin, a.cout);
-  dim3 grid(a.tx * a.ty * a.tz * st * st * st, cdiv(a.cout, ncol), d.N);
+  a.ncb = cdiv(a.cout, ncol);
+  dim3 grid(a.tx * a.ty * a.tz * st * st * st * a.ncb, 1, d.N);
   SEUNET_CHECK(d.N <= 65535, "conv: batch too large");
   // the staging loads use 32-bit byte offsets inside one sample of one source tensor
   for (int i = 0; i < src.n; ++i)
