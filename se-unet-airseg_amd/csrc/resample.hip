@@ -397,6 +397,211 @@ upsample2_bwd_tiled_kernel(const T* __restrict__ g_out, int C, T* g_in, int accu
   }
 }
 
+// z-marching form of the tiled kernel (the one the network uses when every coarse extent is >= 4).  The tiled kernel
+// above gives each coarse plane its own block, so every fine plane is fetched by the ~2 coarse planes it feeds and the
+// interpolation ranges are re-derived per block.  Here a block owns TY x 16 coarse (y, x) positions and a run of ZS
+// coarse planes and walks the fine planes under it ONCE, in order: a fine plane is reduced over y (global loads -> LDS)
+// and x (LDS -> registers) to the block's coarse footprint, and that partial is added to the two coarse planes it feeds
+// (weights 1-lam / lam of ac_src), held in two rotating register accumulators; a coarse plane is stored when the walk
+// has passed it.  Every range and weight is evaluated once per block.
+constexpr int UM_TX = 16, UM_XF = 40, UM_K = 6;   // coarse x per block; fine x columns under them; candidates per coarse index
+__device__ __forceinline__ void ac_exact(int i, float rs, int in, int out, int& lo, int& n, float (&w)[UM_K]) {
+  // the contiguous fine indices o with ac_src(o).i0 == i or .i1 == i, and their weights (<= 5 for in >= 4)
+  int l, h;
+  ac_range(i, rs, out, l, h);
+  int i0, i1; float lam;
+  for (;; ++l) { ac_src(l, rs, in, i0, i1, lam); if (i1 >= i || l >= h) break; }
+  for (;; --h) { ac_src(h, rs, in, i0, i1, lam); if (i0 <= i || h <= l) break; }
+  lo = l;
+  n = h - l + 1 < UM_K ? h - l + 1 : UM_K;
+#pragma unroll
+  for (int k = 0; k < UM_K; ++k) w[k] = k < n ? ac_weight(l + k, i, rs, in) : 0.f;
+}
+template <typename T, int TY>
+__global__ void __launch_bounds__(256, 2)
+upsample2_bwd_march_kernel(const T* __restrict__ g_out, int C, T* g_in, int accumulate, int D, int H, int W, int ZS) {
+  extern __shared__ __attribute__((aligned(16))) float us[];   // [2][TY][UM_XF][C]: one buffer per fine plane, alternating
+  __shared__ float wys[TY][UM_K];
+  __shared__ int yls[TY], nys[TY];
+  const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
+  const int x0 = blockIdx.x * UM_TX, y0 = blockIdx.y * TY;
+  const int nseg = (D + ZS - 1) / ZS;
+  const int seg = blockIdx.z % nseg;
+  const long long n = blockIdx.z / nseg;
+  const int zc0 = seg * ZS, zc1 = zc0 + ZS < D ? zc0 + ZS : D;
+  const int x1 = (x0 + UM_TX < W ? x0 + UM_TX : W) - 1;
+  int i0, i1; float lam;
+  // fine x columns / fine planes that feed this block (exact: first index whose upper target reaches the block, last whose
+  // lower target is still inside)
+  int xf0, xf1, t;
+  ac_range(x0, rx, Wo, xf0, t);
+  for (;; ++xf0) { ac_src(xf0, rx, W, i0, i1, lam); if (i1 >= x0 || xf0 >= Wo - 1) break; }
+  ac_range(x1, rx, Wo, t, xf1);
+  for (;; --xf1) { ac_src(xf1, rx, W, i0, i1, lam); if (i0 <= x1 || xf1 <= xf0) break; }
+  const int nxf = xf1 - xf0 + 1 < UM_XF ? xf1 - xf0 + 1 : UM_XF;
+  int zf0, zf1;
+  ac_range(zc0, rz, Do, zf0, t);
+  for (;; ++zf0) { ac_src(zf0, rz, D, i0, i1, lam); if (i1 >= zc0 || zf0 >= Do - 1) break; }
+  ac_range(zc1 - 1, rz, Do, t, zf1);
+  for (;; --zf1) { ac_src(zf1, rz, D, i0, i1, lam); if (i0 <= zc1 - 1 || zf1 <= zf0) break; }
+  if (threadIdx.x < TY) {
+    const int y = y0 + (int)threadIdx.x;
+    float w[UM_K];
+    int lo = 0, cnt = 0;
+    if (y < H) ac_exact(y, ry, H, Ho, lo, cnt, w);
+    yls[threadIdx.x] = lo; nys[threadIdx.x] = cnt;
+#pragma unroll
+    for (int k = 0; k < UM_K; ++k) wys[threadIdx.x][k] = (y < H && k < cnt) ? w[k] : 0.f;
+  }
+  // this thread's two phase-2 items (coarse y, coarse x, 8 channels): x range and weights, output pointer
+  constexpr int NI = 1;     // TY * 16 * G = 256 items
+  float wx[NI][UM_K];
+  int xrel[NI], qoff[NI];
+  bool live[NI];
+  long long pofs[NI];
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int item = threadIdx.x + 256 * it;
+    const int g = item % G;
+    const int r = item / G;
+    const int xi = r % UM_TX, yi = r / UM_TX;
+    const int x = x0 + xi, y = y0 + yi;
+    live[it] = yi < TY && x < W && y < H;
+    int lo = xf0, cnt = 0;
+    if (live[it]) ac_exact(x, rx, W, Wo, lo, cnt, wx[it]);
+    else {
+#pragma unroll
+      for (int k = 0; k < UM_K; ++k) wx[it][k] = 0.f;
+    }
+    // columns beyond the staged range carry zero weight; clamp the window into the stage so every read stays inside it
+    xrel[it] = lo - xf0;
+    if (xrel[it] < 0) xrel[it] = 0;
+    if (xrel[it] > UM_XF - UM_K) xrel[it] = UM_XF - UM_K;
+    if (live[it] && xrel[it] != lo - xf0) {   // re-derive the weights for the clamped window (border tiles only)
+#pragma unroll
+      for (int k = 0; k < UM_K; ++k) wx[it][k] = ac_weight(xf0 + xrel[it] + k, x, rx, W);
+    }
+    qoff[it] = ((yi < TY ? yi : 0) * UM_XF + xrel[it]) * C + g * 8;
+    pofs[it] = (((n * D) * H + y) * (long long)W + x) * C + g * 8;   // + z * H * W * C
+  }
+  float accA[NI][8], accB[NI][8];
+#pragma unroll
+  for (int it = 0; it < NI; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { accA[it][j] = 0.f; accB[it][j] = 0.f; }
+  ac_src(zf0, rz, D, i0, i1, lam);
+  int cur = i0;                                   // accA <-> coarse plane cur, accB <-> cur + 1
+  const long long plane = (long long)H * W * C;
+  auto flush = [&](int z, float (&acc)[NI][8]) {
+    if (z < zc0 || z >= zc1) return;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      if (!live[it]) continue;
+      T* p = g_in + pofs[it] + z * plane;
+      float o[8];
+      if (accumulate) {
+        load8(p, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += acc[it][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = acc[it][j];
+      }
+      store8(p, o);
+    }
+  };
+  __syncthreads();
+  // phase-1 items of this thread (coarse row, fine column, 8 channels), fixed for the whole walk: TY * G = 16, so
+  // TY * nxf * G <= 640 -> 3 per thread
+  constexpr int N1 = 3, KY = 5;
+  int gofs[N1];           // element offset of the item's first fine row inside a fine plane (< 2^31: checked by the launcher); < 0: no item
+  int uofs[N1], ycnt[N1], yrow[N1];
+#pragma unroll
+  for (int it = 0; it < N1; ++it) {
+    const int item = threadIdx.x + 256 * it;
+    const int g = item % G;
+    const int r = item / G;
+    const int xi = r % nxf, yi = r / nxf;
+    const bool on = item < TY * nxf * G;
+    const int yy = on ? yi : 0;
+    gofs[it] = on ? (yls[yy] * Wo + (xf0 + xi)) * C + g * 8 : -1;
+    uofs[it] = (yy * UM_XF + xi) * C + g * 8;
+    ycnt[it] = on ? (nys[yy] < KY ? nys[yy] : KY) : 0;
+    yrow[it] = yy;
+  }
+  Pack8<T> raw[N1][KY];
+  auto issue = [&](int zo) {
+    const T* gz = g_out + ((n * Do + zo) * (long long)Ho) * Wo * C;
+#pragma unroll
+    for (int it = 0; it < N1; ++it)
+#pragma unroll
+      for (int k = 0; k < KY; ++k)
+        if (k < ycnt[it])   // uniform base + 32-bit byte offset: one address register per load, not a 64-bit pair
+          load8p(reinterpret_cast<const T*>(reinterpret_cast<const char*>(gz) + (unsigned)((gofs[it] + k * Wo * C) * (int)sizeof(T))), raw[it][k]);
+  };
+  issue(zf0);
+  int buf = 0;
+  for (int zo = zf0; zo <= zf1; ++zo) {
+    ac_src(zo, rz, D, i0, i1, lam);
+    if (i0 > cur) {                               // (the source index advances by at most one per fine plane: scale < 1)
+      flush(cur, accA);
+#pragma unroll
+      for (int it = 0; it < NI; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { accA[it][j] = accB[it][j]; accB[it][j] = 0.f; }
+      cur = i0;
+    }
+    const float wA = (1.f - lam) + (i1 == i0 ? lam : 0.f), wB = i1 != i0 ? lam : 0.f;
+    // phase 1: the fetched rows of fine plane zo reduced over y into this plane's LDS buffer
+    float* ub = us + buf * (TY * UM_XF * C);
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+      if (gofs[it] < 0) continue;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KY; ++k) {
+        if (k < ycnt[it]) {
+          float v[8];
+          unpack8(raw[it][k], v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += wys[yrow[it]][k] * v[j];
+        }
+      }
+      float* q = ub + uofs[it];
+      reinterpret_cast<float4*>(q)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      reinterpret_cast<float4*>(q)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    __syncthreads();     // the one barrier per fine plane: the buffers alternate, so plane zo + 2 overwrites this one only
+                         // after every thread has passed the barrier of plane zo + 1, i.e. finished reading it
+    if (zo < zf1) issue(zo + 1);   // in flight during phase 2
+    // phase 2: reduce x from LDS, add to the two coarse planes this fine plane feeds
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      float pz[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pz[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < UM_K; ++k) {
+        const float w = wx[it][k];
+        if (xrel[it] + k < nxf) {
+          const float* q = ub + qoff[it] + k * C;
+          const float4 a = reinterpret_cast<const float4*>(q)[0], b = reinterpret_cast<const float4*>(q)[1];
+          pz[0] += w * a.x; pz[1] += w * a.y; pz[2] += w * a.z; pz[3] += w * a.w;
+          pz[4] += w * b.x; pz[5] += w * b.y; pz[6] += w * b.z; pz[7] += w * b.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { accA[it][j] += wA * pz[j]; accB[it][j] += wB * pz[j]; }
+    }
+    buf ^= 1;
+  }
+  flush(cur, accA);
+  flush(cur + 1, accB);
+}
+
 // ---------------- side map up-sampling to NCDHW (block-level API / tests only) ------------------
 __global__ void side_upsample_kernel(const float* __restrict__ side, int C, int scale,
                                      float* __restrict__ out, int c_total, int c_off, int D, int H, int W,
@@ -683,9 +888,36 @@ static void upsample2_bwd_tiled(const void* g_out, int C, void* g_in, int accumu
   upsample2_bwd_tiled_kernel<T, TY><<<grid, 256, lds, s>>>((const T*)g_out, C, (T*)g_in, accumulate, d.D, d.H, d.W);
 }
 
+template <typename T, int TY>
+static int upsample2_bwd_march(const void* g_out, int C, void* g_in, int accumulate, Dims d, int ZS, hipStream_t s) {
+  const size_t lds = (size_t)2 * 128 * UM_XF * sizeof(float);   // 40 KB: four workgroups per CU
+  static unsigned long long cfg = 0;
+  if (first_use_on_device(cfg))
+    SEUNET_HIP(hipFuncSetAttribute((const void*)upsample2_bwd_march_kernel<T, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nseg = (d.D + ZS - 1) / ZS;
+  dim3 grid((unsigned)((d.W + UM_TX - 1) / UM_TX), (unsigned)((d.H + TY - 1) / TY), (unsigned)(d.N * nseg));
+  upsample2_bwd_march_kernel<T, TY><<<grid, 256, lds, s>>>((const T*)g_out, C, (T*)g_in, accumulate, d.D, d.H, d.W, ZS);
+  return 0;
+}
+
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate, Dims d,
                          hipStream_t s) {
   SEUNET_CHECK(C % 8 == 0, "upsample2: C=%d must be a multiple of 8", C);
+  // z-marching kernel: TY * C = 128 (256 phase-2 items of 8 channels = 1 per thread), LDS = 2 x 128 * 40 floats = 40 KB
+  // (16-bit storage only: the f32 parity mode would hold 200 registers of fetched rows; it stays on the tiled kernel)
+  if (dtype_size(dtype) == 2 && (C == 32 || C == 64 || C == 128) && d.D >= 4 && d.H >= 4 && d.W >= 4 &&
+      (long long)4 * d.H * d.W * C < (1LL << 31) && getenv("SEUNET_UP_TILED") == nullptr) {
+    const int ZS = d.D >= 32 ? 8 : 4;
+    const int nseg = (d.D + ZS - 1) / ZS;
+    SEUNET_CHECK((long long)d.N * nseg <= 65535, "upsample2_bwd: batch too large");
+    int rc = 0;
+    SEUNET_DTYPE_SWITCH(dtype, { rc = C == 32 ? upsample2_bwd_march<T, 4>(g_out, C, g_in, accumulate, d, ZS, s)
+                                    : C == 64 ? upsample2_bwd_march<T, 2>(g_out, C, g_in, accumulate, d, ZS, s)
+                                              : upsample2_bwd_march<T, 1>(g_out, C, g_in, accumulate, d, ZS, s); });
+    if (rc) return rc;
+    SEUNET_LAUNCH_CHECK();
+    return 0;
+  }
   // tiled separable kernel: LDS = TY * 44 * C floats <= 45 KB with TY = 4 up to 64 channels, TY = 2 up to 128
   const bool tiled = C <= 128 && (long long)d.N * d.D <= 65535 && d.W >= 2;
   if (tiled) {

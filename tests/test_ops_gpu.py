@@ -300,6 +300,10 @@ def test_maxpool_and_upsample(S, dtype):
     u_ref.backward(gu)
     assert_close(S.from_cl(S.upsample2_fwd(S.to_cl(y.detach().cuda(), dtype))), u_ref, dtype, "upsample")
     assert_close(S.from_cl(S.upsample2_bwd(S.to_cl(gu.cuda(), dtype))), y.grad, dtype, "upsample bwd")
+    # accumulate form (the gradient buffer already holds another consumer's contribution)
+    init = rnd(dtype, gen(n, c, d, h, w, seed=43))
+    got = S.from_cl(S.upsample2_bwd(S.to_cl(gu.cuda(), dtype), g_in=S.to_cl(init.cuda(), dtype)))
+    assert_close(got, y.grad + init, dtype, "upsample bwd +=")
 
 
 def test_maxpool_tie_goes_to_first(S):
@@ -447,10 +451,13 @@ def test_conv_stream_weight_gradient(S, case, shape):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(1, 32, 5, 7, 70), (2, 64, 3, 4, 33), (1, 8, 1, 1, 2), (1, 16, 2, 9, 64), (1, 128, 2, 3, 5)])
+@pytest.mark.parametrize("shape", [(1, 32, 5, 7, 70), (2, 64, 3, 4, 33), (1, 8, 1, 1, 2), (1, 16, 2, 9, 64), (1, 128, 2, 3, 5),
+                                   (2, 64, 9, 4, 33), (1, 128, 4, 6, 20), (1, 32, 40, 9, 17), (1, 32, 33, 16, 16), (1, 64, 4, 4, 4)])
 def test_upsample2_forward_backward_shapes(S, dtype, shape):
     """x2 trilinear (align_corners=True) on the tiled kernels: more than one 128-voxel x-chunk, odd extents, single rows,
-    and the 128-channel case (width x2) that takes the gather kernel."""
+    the 128-channel case (width x2); the backward takes the z-marching kernel when C is 32 / 64 / 128 and every coarse
+    extent is >= 4 (ragged y / x tiles, several z segments, a ragged last segment), the per-plane tiled kernel or the gather
+    kernel otherwise."""
     n, c, d, h, w = shape
     y = rnd(dtype, gen(n, c, d, h, w, seed=41)).requires_grad_(True)
     u_ref = F.interpolate(y, scale_factor=2, mode="trilinear", align_corners=True)
