@@ -6,9 +6,16 @@
  * reference code it replaces.  Conventions:
  *   - plain C, no torch types: raw device pointers, explicit shapes, a dtype enum, a hipStream_t;
  *   - every function returns 0 on success, non-zero on error (message: seunet_last_error(), thread
- *     local); nothing throws across the ABI, nothing allocates/frees caller memory, nothing
- *     synchronises the device; workspaces are caller-owned;
- *   - re-entrant: no global mutable state, everything is parameterised by (pointers, stream);
+ *     local); nothing throws across the ABI; every tensor and workspace is caller-owned and the
+ *     launches themselves neither allocate nor synchronise;
+ *   - what the library keeps per process, all of it created lazily on first need and none of it per call:
+ *       (1) per device, one 4-KB page of zeros (hipMalloc + hipMemset, i.e. one device synchronisation, the first time
+ *           a kernel that pads through it runs on that device -- or up front by seunet_init);
+ *       (2) per kernel instantiation, a bit mask of the devices on which hipFuncSetAttribute (LDS above 64 KB) has run;
+ *       (3) the opt-in seunet_prof_* recorder (process-wide, off by default; the per-launch-group timer of bench.py);
+ *       (4) the diagnostic environment switches SEUNET_NO_STREAM / SEUNET_UP_TILED, read when a plan is built.
+ *     Apart from these everything is parameterised by (pointers, stream) and calls are re-entrant across threads and
+ *     streams; a graph object (seunet_net_forward_capture) is owned by the caller like any other handle;
  *   - activations inside the library are channels-last [N][D][H][W][C], C a multiple of 8, f32, bf16 or
  *     f16 (SEUNET_F32 / SEUNET_BF16 / SEUNET_F16); parameters, logits, losses and gradients of parameters are
  *     f32 in the PyTorch layouts of the reference's state_dict.
@@ -34,6 +41,9 @@ typedef struct seunet_dims { int n, d, h, w; } seunet_dims;
 
 int seunet_version(void);
 const char* seunet_last_error(void);
+/* Optional: create the per-device state (1) above for `device` now, so that no later call synchronises the device
+ * (call it before stream capture or a timed region; the training / inference entry points work without it). */
+int seunet_init(int device);
 
 /* ---- layout: reference tensors are NCDHW f32 (SE_UNet.py:181 "x: 1 2 128 128 128") ---------------- */
 int seunet_pack_cl(int dtype, const float* in_ncdhw, int c, void* out_cl, int c_pad, seunet_dims dims, seunet_stream_t s);

@@ -30,9 +30,9 @@ with torch.no_grad():
     t = sync_time(lambda: m(xw), 5)
 print("forward only 4x128^3 bf16: %.2f ms -> %.1f M voxels/s" % (t * 1e3, 4 * 128 ** 3 / t / 1e6), flush=True)
 del m
-# configs[4] shape on one GPU: 2x width, 160^3, bf16 (fp16 storage is not implemented; same MFMA rate and bytes)
-for B in (1, 2):
-    m2 = A.SE_UNet(2, 1, width_mult=2, act_dtype="bf16").cuda().eval()
+# configs[4] on one GPU: 2x width, 160^3, fp16 activation storage (static loss scale 65536) and the bf16 mode beside it
+for B, dt_ in ((1, "fp16"), (2, "fp16"), (2, "bf16")):
+    m2 = A.SE_UNet(2, 1, width_mult=2, act_dtype=dt_).cuda().eval()
     x2 = torch.rand(B, 2, 160, 160, 160, device="cuda")
     lab = (torch.rand(B, 1, 160, 160, 160, device="cuda") < 0.03).float()
     def step():
@@ -42,6 +42,19 @@ for B in (1, 2):
         A.fused_stage_loss(1, e, d, lab).backward()
     t = sync_time(step, 3)
     ok = all(torch.isfinite(p.grad).all() for n, p in m2.named_parameters() if not n.startswith("dc62."))
-    print("configs[4] shape: width x2, %dx160^3 bf16 fwd+bwd: %.1f ms -> %.1f M voxels/s (finite grads: %s, peak mem %.1f GB)"
-          % (B, t * 1e3, B * 160 ** 3 / t / 1e6, bool(ok), torch.cuda.max_memory_allocated() / 1e9), flush=True)
+    print("configs[4]: width x2, %dx160^3 %s fwd+bwd: %.1f ms -> %.1f M voxels/s (finite grads: %s, peak mem %.1f GB)"
+          % (B, dt_, t * 1e3, B * 160 ** 3 / t / 1e6, bool(ok), torch.cuda.max_memory_allocated() / 1e9), flush=True)
     del m2, x2, lab
+
+# SURVEY 8(f2)/(f4) on a 512^3 probability volume: double-threshold sweep, largest 26-connected component, hole fill
+g = torch.Generator(device="cuda").manual_seed(5)
+prob = torch.rand((512, 512, 512), generator=g, device="cuda", dtype=torch.float64)
+prob = torch.nn.functional.avg_pool3d(prob[None, None].float(), 5, 1, 2)[0, 0].double()     # blobs instead of salt and pepper
+for name, fn in (("double_threshold_iteration (h 0.5 / l 0.4)", lambda: A.double_threshold_iteration(prob, 0.5, 0.4)),
+                 ("largest_component (26-conn)", lambda: A.largest_component((prob > 0.5).to(torch.uint8))),
+                 ("maximum_3d (largest 26-conn + 2-D hole fill)", lambda: A.maximum_3d((prob > 0.5).to(torch.uint8)))):
+    try:
+        t = sync_time(fn, 3)
+        print("512^3 %s: %.1f ms" % (name, t * 1e3), flush=True)
+    except Exception as e:        # (argument conventions differ between the wrappers; the tests are the reference for them)
+        print("512^3 %s: skipped (%s)" % (name, str(e)[:80]), flush=True)

@@ -333,6 +333,7 @@ class CapturedForward:
         d2 = self.drop2.data_ptr() if training else None
         cur = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(cur)
+        _lib.check(lib.seunet_init(self.device.index if self.device.index is not None else torch.cuda.current_device()), "init")
         with torch.cuda.stream(self._stream):
             args = (C.byref(self.desc), parr, self.x.data_ptr(), d1, d2, self.pred0.data_ptr(), self.pred1.data_ptr(),
                     self.ws.data_ptr(), self.ws_bytes, _lib.stream_ptr())

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "seunet_prof_enable": (_i, [_i]),
     "seunet_prof_enable_filtered": (_i, [C.c_char_p]),
     "seunet_prof_report": (_i, [C.c_char_p, _sz]),
+    "seunet_init": (_i, [_i]),
     "seunet_net_forward_capture": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, C.POINTER(C.c_void_p)]),
     "seunet_graph_launch": (_i, [_vp, _vp]),
     "seunet_graph_destroy": (_i, [_vp]),

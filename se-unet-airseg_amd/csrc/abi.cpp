@@ -23,8 +23,20 @@ extern "C" {
 // diagnostic hook (not part of the public header): device buffer of 8 u64 that -DSEUNET_STAMP builds add cycle sums to
 int seunet_debug_set_buffer(void* p) { seunet::g_conv_debug = reinterpret_cast<unsigned long long*>(p); return 0; }
 
-int seunet_version(void) { return 100; }
+int seunet_version(void) { return 200; }
 const char* seunet_last_error(void) { return get_error(); }
+
+int seunet_init(int device) {
+  int count = 0, prev = 0;
+  SEUNET_HIP(hipGetDeviceCount(&count));
+  SEUNET_CHECK(device >= 0 && device < count, "init: device %d out of range (%d visible)", device, count);
+  SEUNET_HIP(hipGetDevice(&prev));
+  SEUNET_HIP(hipSetDevice(device));
+  const void* page = seunet::device_zero_page();
+  (void)hipSetDevice(prev);
+  SEUNET_CHECK(page != nullptr, "init: could not allocate the zero page on device %d", device);
+  return 0;
+}
 
 int seunet_pack_cl(int dtype, const float* in, int c, void* out, int c_pad, seunet_dims dims, seunet_stream_t s) {
   SEUNET_CHECK(in && out, "pack_cl: null tensor");
