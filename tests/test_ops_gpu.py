@@ -282,6 +282,23 @@ def test_cat_epilogue_with_recomputed_x_branch(S, dtype, inch, c):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c", [8, 32, 64, 128, 24])
+def test_maxpool_ties_and_channel_counts(S, dtype, c):
+    """Max-pool forward / backward on inputs FULL of ties (small integers): the gradient goes to the first maximum of the
+    window in (z, y, x) scan order, like PyTorch's CPU kernel."""
+    n, d, h, w = 2, 6, 4, 10
+    g0 = torch.Generator().manual_seed(50 + c)
+    x = torch.randint(0, 3, (n, c, d, h, w), generator=g0).float().requires_grad_(True)
+    p_ref = F.max_pool3d(x, 2, 2)
+    g = rnd(dtype, gen(*p_ref.shape, seed=51))
+    p_ref.backward(g)
+    xc = S.to_cl(x.detach().cuda(), dtype)
+    assert torch.equal(S.from_cl(S.maxpool_fwd(xc)).cpu().float(), p_ref.detach())
+    gi = S.from_cl(S.maxpool_bwd(xc, S.to_cl(g.cuda(), dtype))).cpu().float()
+    assert torch.equal(gi, x.grad), float((gi - x.grad).abs().max())
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_maxpool_and_upsample(S, dtype):
     n, c, d, h, w = 2, 16, 4, 6, 10
     x = rnd(dtype, gen(n, c, d, h, w, seed=28)).requires_grad_(True)
