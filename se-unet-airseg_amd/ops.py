@@ -377,24 +377,88 @@ def _conv_stats(srcs, weight, bias, dilation, impl, cin=None):
     return raw, mean, rstd
 
 
-@torch.no_grad()
+def _side_grad_to_block(g_s: torch.Tensor, down_sample: int) -> torch.Tensor:
+    """Transpose of ``side_upsample``: (N, 2, D*s, H*s, W*s) -> (N, D, H, W, 2) float32 (the transposed align_corners
+    interpolation is the one the heads use: ``seunet_head_bwd``, one call per side channel)."""
+    if down_sample == 1:
+        return g_s.permute(0, 2, 3, 4, 1).contiguous().float()
+    lvl = {2: 1, 4: 2, 8: 3}[down_sample]
+    parts = [head_bwd(g_s[:, c:c + 1].contiguous(), lvl + 1)[0][lvl] for c in range(g_s.shape[1])]
+    return torch.stack(parts, dim=-1).contiguous()
+
+
+class _GatedBlockFn(torch.autograd.Function):
+    """SSEConv / SSEConv2 (SE_UNet.py:9-35, 51-82) as a differentiable unit: the network's kernels called block-wise
+    (conv + statistics, fused epilogue; backward = the two InstanceNorm passes, weight gradient, data gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w_se, w_se2, w2, b2, dilation, down_sample, slope):
+        from .SE_UNet import _default_conv_impl
+        impl = _default_conv_impl()
+        xc = to_cl(x, _block_dtype())
+        raw, mean, rstd = _conv_stats([xc], w1, b1, dilation, impl, cin=x.shape[1])
+        e, side = gate_epilogue_fwd(raw, mean, rstd, w_se, w_se2, w2, b2, slope)
+        ctx.save_for_backward(xc, raw, mean, rstd, w1, w_se, w_se2 if w_se2 is not None else w_se, w2, b2)
+        ctx.meta = (dilation, down_sample, slope, impl, x.shape[1], w_se2 is not None)
+        return from_cl(e), side_upsample(side, down_sample)
+
+    @staticmethod
+    def backward(ctx, g_e, g_s):
+        xc, raw, mean, rstd, w1, w_se, w_se2, w2, b2 = ctx.saved_tensors
+        dilation, down_sample, slope, impl, cin, two = ctx.meta
+        code = _code(raw)
+        g_ec = None if g_e is None else to_cl(g_e.contiguous().float(), code)
+        g_side = None if g_s is None else _side_grad_to_block(g_s.contiguous().float(), down_sample)
+        out = gate_epilogue_bwd(raw, mean, rstd, w_se, w_se2 if two else None, w2, b2, slope, g_e=g_ec, g_side=g_side)
+        cout = w1.shape[0]
+        dw1 = conv3d_wgrad([xc], out["draw"], cin, cout, 27, dilation, impl)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            (g,), _, _ = conv3d([out["draw"]], w1, None, dilation, impl, transpose_flip=True)
+            gx = from_cl(g, cin)
+        # conv1.bias feeds an affine-less InstanceNorm: its gradient is identically zero (SURVEY Q4)
+        return (gx, dw1, torch.zeros(cout, device=raw.device), out["dw_se"].view_as(w_se),
+                out["dw_se2"].view_as(w_se) if two else None, out["dw_side"].view_as(w2), out["db_side"].view_as(b2),
+                None, None, None)
+
+
+class _CatBlockFn(torch.autograd.Function):
+    """CATConv (SE_UNet.py:37-49) as a differentiable unit."""
+
+    @staticmethod
+    def forward(ctx, x, w1, slope):
+        from .SE_UNet import _default_conv_impl
+        impl = _default_conv_impl()
+        xc = to_cl(x, _block_dtype())
+        raw, mean, rstd = _conv_stats([xc], w1, None, 1, impl, cin=x.shape[1])
+        ctx.save_for_backward(xc, raw, mean, rstd, w1)
+        ctx.meta = (slope, impl, x.shape[1])
+        return from_cl(cat_epilogue_fwd(raw, mean, rstd, slope=slope))
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, raw, mean, rstd, w1 = ctx.saved_tensors
+        slope, impl, cin = ctx.meta
+        dx, _ = cat_epilogue_bwd(to_cl(g.contiguous().float(), _code(raw)), raw, mean, rstd, slope=slope)
+        dw1 = conv3d_wgrad([xc], dx, cin, w1.shape[0], 1, 1, impl)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            (gg,), _, _ = conv3d([dx], w1, None, 1, impl, transpose_flip=True)
+            gx = from_cl(gg, cin)
+        return gx, dw1, None
+
+
 def gated_block_forward(mod, x: torch.Tensor):
-    """(e0, e1) of SE_UNet.py:24-35 / 68-82 for an NCDHW input on the GPU."""
+    """(e0, e1) of SE_UNet.py:24-35 / 68-82 for an NCDHW input on the GPU; differentiable w.r.t. the input and the block's
+    parameters (the whole-network path does not go through here: it is ONE native call per direction)."""
     if not x.is_cuda:
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
-    from .SE_UNet import _default_conv_impl
-    xc = to_cl(x, _block_dtype())
-    raw, mean, rstd = _conv_stats([xc], mod.conv1.weight, mod.conv1.bias, mod.dilation, _default_conv_impl(), cin=x.shape[1])
-    e, side = gate_epilogue_fwd(raw, mean, rstd, mod.conv_se.weight, getattr(mod, "conv_se2", None) and mod.conv_se2.weight,
-                                mod.conv2.weight, mod.conv2.bias, 0.01)
-    return from_cl(e), side_upsample(side, mod.down_sample)
+    w_se2 = mod.conv_se2.weight if getattr(mod, "conv_se2", None) is not None else None
+    return _GatedBlockFn.apply(x.contiguous().float(), mod.conv1.weight, mod.conv1.bias, mod.conv_se.weight, w_se2,
+                               mod.conv2.weight, mod.conv2.bias, mod.dilation, mod.down_sample, 0.01)
 
 
-@torch.no_grad()
 def cat_block_forward(mod, x: torch.Tensor):
     if not x.is_cuda:
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
-    from .SE_UNet import _default_conv_impl
-    xc = to_cl(x, _block_dtype())
-    raw, mean, rstd = _conv_stats([xc], mod.conv1.weight, None, 1, _default_conv_impl(), cin=x.shape[1])
-    return from_cl(cat_epilogue_fwd(raw, mean, rstd))
+    return _CatBlockFn.apply(x.contiguous().float(), mod.conv1.weight, 0.01)

@@ -322,9 +322,43 @@ def test_block_modules_standalone(A, orc):
         x = orc.synthetic_batch(1, (16, 16, 16), 2, seed=11)["image"]
         e_ref, s_ref = o._gated("ec1", x)
         e, s = m.ec1(x.cuda())
-        assert float((e.cpu() - e_ref).abs().max()) < 1e-4 and float((s.cpu() - s_ref).abs().max()) < 1e-4
+        assert float((e.detach().cpu() - e_ref.detach()).abs().max()) < 1e-4 and float((s.detach().cpu() - s_ref.detach()).abs().max()) < 1e-4
         t = torch.rand(1, 56, 8, 8, 8)
-        assert float((m.ec33(t.cuda()).cpu() - o._cat("ec33", t)).abs().max()) < 1e-4
+        assert float((m.ec33(t.cuda()).detach().cpu() - o._cat("ec33", t).detach()).abs().max()) < 1e-4
+    finally:
+        os.environ.pop("SEUNET_DTYPE", None)
+
+
+@pytest.mark.parametrize("name,cin,shape", [("ec1", 2, (16, 16, 16)), ("ec5", 32, (8, 16, 16)), ("dc2", 64, (8, 8, 8)), ("ec33", 56, (8, 8, 16))])
+def test_block_modules_are_differentiable_fp32(A, orc, name, cin, shape):
+    """SSEConv / SSEConv2 / CATConv used on their own (SE_UNet.py:9-82) back-propagate like the reference's modules: the
+    gradients w.r.t. the input and every parameter of the block against the float64 oracle block, for a loss that uses
+    BOTH outputs (the gated tensor and the up-sampled 2-channel side map; down_sample 1, 2 and 4, dilation 1 and 2)."""
+    os.environ["SEUNET_DTYPE"] = "fp32"
+    try:
+        o = orc.build_oracle(2, 1, 1, seed=0).double()
+        m = build(A, orc, 2, "fp32")
+        g0 = torch.Generator().manual_seed(77)
+        x = torch.rand((2, cin) + shape, generator=g0)
+        xo = x.double().requires_grad_(True)
+        xm = x.cuda().requires_grad_(True)
+        blk_o, blk_m = getattr(o, name), getattr(m, name)
+        if name == "ec33":
+            out_o, out_m = (o._cat(name, xo),), (blk_m(xm),)
+        else:
+            out_o, out_m = o._gated(name, xo), blk_m(xm)
+        ws = [torch.rand(t.shape, generator=g0) - 0.5 for t in out_o]
+        sum((t * w.double()).sum() for t, w in zip(out_o, ws)).backward()
+        sum((t * w.cuda()).sum() for t, w in zip(out_m, ws)).backward()
+        for a, b in zip(out_m, out_o):
+            assert float((a.detach().cpu().double() - b.detach()).abs().max()) < 1e-4
+        rel = lambda a, r: float((a.detach().cpu().double() - r).norm() / (r.norm() + 1e-30))
+        assert rel(xm.grad, xo.grad) < 2e-4, ("x", rel(xm.grad, xo.grad))
+        for (n_, p_m), (_, p_o) in zip(blk_m.named_parameters(), blk_o.named_parameters()):
+            if n_ == "conv1.bias":      # identically zero (affine-less InstanceNorm follows); the oracle holds rounding noise
+                assert float(p_m.grad.abs().max()) == 0.0
+                continue
+            assert rel(p_m.grad, p_o.grad) < 2e-4, (n_, rel(p_m.grad, p_o.grad))
     finally:
         os.environ.pop("SEUNET_DTYPE", None)
 
