@@ -42,7 +42,7 @@ def window_table(shape: Sequence[int], cube: int = 128, step: int = 64, pad_to_b
     return pos
 
 
-def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_dup: int, graph: bool = False) -> torch.Tensor:
+def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_dup: int, graph: bool = False, group=None) -> torch.Tensor:
     if not x.is_cuda:
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
     if x.dim() != 5 or x.shape[0] != 1:
@@ -51,6 +51,14 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
     x = x.contiguous().float()
     _, C_, X, Y, Z = x.shape
     max_call = 64                                       # windows per native call (kernel-argument table)
+    # one case over several GPUs (one process per GPU, every rank holds the volume): the BATCHES of the window list are
+    # dealt round-robin, each rank accumulates its windows, and the float64 accumulators are summed by one all-reduce
+    # before the division by the overlap count -- the only exchange step of the loop
+    world, rank, pg = 1, 0, None
+    if group is not None and group is not False:
+        import torch.distributed as dist
+        pg = None if group is True else group
+        world, rank = dist.get_world_size(pg), dist.get_rank(pg)
     with torch.cuda.device(x.device):
         st = _lib.stream_ptr()
         acc = torch.zeros((X, Y, Z), dtype=torch.float64, device=x.device)
@@ -60,7 +68,9 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
         if graph and len(pos) >= 2 * batch:
             from .SE_UNet import CapturedForward
             cap = CapturedForward(model, batch, (cube, cube, cube))
-        for i in range(0, len(pos), batch):
+        for bi, i in enumerate(range(0, len(pos), batch)):
+            if bi % world != rank:
+                continue
             chunk = pos[i:i + batch]
             use_cap = cap is not None and len(chunk) == batch
             xin = cap.x if use_cap else torch.empty((len(chunk), C_, cube, cube, cube), dtype=torch.float32, device=x.device)
@@ -75,6 +85,9 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
                 arr = _lib.int_array([v for q in sub for v in q])
                 _lib.check(lib.seunet_window_accumulate(p[j:].data_ptr(), 1, len(sub), arr, cube, acc.data_ptr(), X, Y, Z, st),
                            "window_accumulate")
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=pg)
         xs, ys, zs = window_starts(X, cube, step), window_starts(Y, cube, step), window_starts(Z, cube, step)
         out = torch.empty_like(acc)
         _lib.check(lib.seunet_window_finalize(acc.data_ptr(), X, Y, Z, cube, len(xs), _lib.int_array(xs), len(ys), _lib.int_array(ys),
@@ -84,16 +97,20 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
 
 @torch.no_grad()
 def sliding_window_predict(model, x: torch.Tensor, cube: int = 128, step: int = 64, batch: int = 1,
-                           return_tensor: bool = False, graph: bool = False):
+                           return_tensor: bool = False, graph: bool = False, group=None):
     """prediction.py:78-109.  x: (1, C, X, Y, Z) on the GPU.  Returns the overlap-averaged sigmoid(pred1) volume as
     float64 numpy (like the reference's host accumulators), or the float64 CUDA tensor with ``return_tensor=True`` (what
     ``double_threshold_iteration`` takes next, prediction.py:110).  ``batch`` windows go through the network per call
     (the reference uses 1; results are identical in eval mode because InstanceNorm is per sample).  ``graph``: replay the
     forward pass as one recorded HIP graph per batch (``CapturedForward``: same kernels, same bits).  Off by default: on
     MI355X the loop is bound by the kernels, not by their launches (512^3: 0.499 s replayed vs 0.493 s launched one by
-    one at batch 4, 0.656 vs 0.648 s at batch 1); it pays only when the host thread is slow or busy."""
+    one at batch 4, 0.656 vs 0.648 s at batch 1); it pays only when the host thread is slow or busy.
+    ``group`` (``True`` = the default process group, or a ``ProcessGroup``): shard the windows of this ONE case over the
+    ranks (every rank passes the same volume and gets the full result; the window batches are dealt round-robin and the
+    float64 accumulators all-reduced once, RCCL on GPUs).  Eval mode only gives rank-count-independent results
+    (DropLayer draws are per call)."""
     pos = window_table(x.shape[2:], cube, step)
-    out = _assemble(model, x, pos, cube, step, batch, 0, graph)
+    out = _assemble(model, x, pos, cube, step, batch, 0, graph, group)
     return out if return_tensor else out.cpu().numpy()
 
 

@@ -624,6 +624,57 @@ def test_data_parallel_two_gpus_equal_one_gpu_batch2_rccl(A, orc):
     _run_dp_equivalence(A, orc, "nccl")
 
 
+def _window_worker(rank, world, port, q):
+    import os as _os
+    import sys as _sys
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    for p_ in (root, _os.path.join(root, "oracle")):
+        if p_ not in _sys.path:
+            _sys.path.insert(0, p_)
+    import torch as _t
+    import torch.distributed as _dist
+    import seunet_amd as _A
+    import seunet_oracle as _orc
+    from seunet_amd import ddp as _ddp
+    try:
+        _ddp.init_from_env("gloo")
+        _t.cuda.set_device(0)
+        m = _A.SE_UNet(2, 1, act_dtype="fp32")
+        m.load_state_dict(_orc.deterministic_state_dict(2, 1, 1, seed=0))
+        m = m.cuda().eval()
+        x = _orc.synthetic_batch(1, (192, 128, 192), 2, seed=19)["image"].cuda()
+        out = _A.sliding_window_predict(m, x, batch=1, group=True)
+        q.put((rank, out if rank == 0 else None, float(out.sum())))
+        _dist.barrier()
+        _dist.destroy_process_group()
+    except Exception as ex:
+        q.put((rank, repr(ex), None))
+
+
+def test_window_loop_sharded_over_two_ranks_equals_one_rank_gloo_shared_gpu(A, orc):
+    """One case, its 4 windows dealt to two ranks (sharing cuda:0, exchanging over gloo), float64 accumulators all-reduced
+    once before the division: every rank ends with the single-process result (float64 sums in another order: <= 1e-12)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 977) % 2000
+    procs = [ctx.Process(target=_window_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+    assert all(r[2] is not None for r in res), res
+    m = build(A, orc, 2, "fp32")
+    x = orc.synthetic_batch(1, (192, 128, 192), 2, seed=19)["image"].cuda()
+    ref = A.sliding_window_predict(m, x, batch=1)
+    assert len(A.window_table((192, 128, 192))) == 4
+    assert float(np.abs(res[0][1] - ref).max()) <= 1e-12
+    assert abs(res[0][2] - res[1][2]) <= 1e-9 * abs(res[0][2])
+
+
 def test_second_backward_and_input_grad_fail_clearly(A, orc):
     m = build(A, orc, 2, "fp32")
     x = orc.synthetic_batch(1, (16, 16, 16), 2, seed=1)["image"].cuda()
