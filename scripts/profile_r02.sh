@@ -20,3 +20,5 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WA
 done
 python3 scripts/pmc_summary.py $O > $O/pmc_summary.txt
 cat $O/pmc_summary.txt
+timeout -k 10 500 python3 scripts/bench_configs.py > $O/other_configs.txt 2>&1 || true
+tail -12 $O/other_configs.txt
