@@ -777,25 +777,28 @@ int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* d
   return 0;
 }
 
-// dW2 (PyTorch layout (C, in_channel, 1, 1, 1)) = f64 fixed-order sum of the XW block records; one wave per (c, i)
+// dW2 (PyTorch layout (C, in_channel, 1, 1, 1)) = f64 fixed-order sum of the XW block records; one BLOCK per (c, i)
+// (one wave per entry left 16 blocks on the chip walking 4096 records each: 28 us per launch)
 __global__ void __launch_bounds__(256)
 xw_reduce_kernel(const float* __restrict__ part, int records, int C, int in_channel, float* __restrict__ dw) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + wave;          // k = c * 2 + i
-  if (k >= C * 2) return;
+  const int k = blockIdx.x;                     // k = c * 2 + i
   double s = 0.0;
-  for (int r = lane; r < records; r += 64) s += (double)part[(long long)r * (C * 2) + k];
+  for (int r = threadIdx.x; r < records; r += 256) s += (double)part[(long long)r * (C * 2) + k];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ double red[4];
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
   const int c = k >> 1, i = k & 1;
-  if (lane == 0 && i < in_channel) dw[c * in_channel + i] = (float)s;
+  if (threadIdx.x == 0 && i < in_channel) dw[c * in_channel + i] = (float)(((red[0] + red[1]) + red[2]) + red[3]);
 }
 
 int cat_xgrad_records(Dims d) { return d.N * epi_partials(d) * 4; }
 
 int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_channel, float* dw, hipStream_t s) {
   SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_xgrad_reduce: in_channel %d (1 or 2)", in_channel);
-  xw_reduce_kernel<<<cdiv(C * 2, 4), 256, 0, s>>>(xw_partial, records, C, in_channel, dw);
+  xw_reduce_kernel<<<C * 2, 256, 0, s>>>(xw_partial, records, C, in_channel, dw);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
