@@ -834,6 +834,85 @@ int launch_cat_fwd_x(int dtype, const void* raw, const float* mean, const float*
   return 0;
 }
 
+// The aggregation block's forward with the 2x2x2 max-pool that follows it in the encoder (SE_UNet.py:188-189, 197-198,
+// 206-207: ec33 -> pool0, ec63 -> pool1, ec93 -> pool2) written by the same kernel: a thread owns one pooling window x 8
+// channels, computes the block output of its eight voxels (same arithmetic as cat_fwd_kernel<.., true, true>), stores them and
+// their maximum.  The pooled tensor costs one extra 1/8-size store instead of a second read of the full-resolution output.
+// (Rounding is monotonic, so the maximum of the rounded values the separate kernel reads equals the rounded maximum.)
+template <typename T, int LPV>
+__global__ void __launch_bounds__(EPI_THREADS)
+cat_fwd_pool_kernel(const T* __restrict__ raw, const float* __restrict__ mean, const float* __restrict__ rstd,
+                    const T* __restrict__ xin, const float* __restrict__ mean2, const float* __restrict__ rstd2, int C, float slope,
+                    T* __restrict__ out, T* __restrict__ pooled, int D, int H, int W, const float* __restrict__ w2x, int xic) {
+  const int n = blockIdx.y, P = gridDim.x;
+  const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
+  constexpr int VPB = EPI_THREADS / LPV;
+  const int c0 = cg * 8;
+  float mu[8], rs[8], mu2[8], rs2[8], wa[8], wb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[n * C + c0 + j]; rs[j] = rstd[n * C + c0 + j];
+    mu2[j] = mean2[n * C + c0 + j]; rs2[j] = rstd2[n * C + c0 + j];
+    wa[j] = w2x[(c0 + j) * xic];
+    wb[j] = xic > 1 ? w2x[(c0 + j) * xic + 1] : 0.f;
+  }
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long long V = (long long)D * H * W, Vo = (long long)Do * Ho * Wo;
+  const long long stride = (long long)P * VPB;
+  for (long long cv = (long long)blockIdx.x * VPB + vb; cv < Vo; cv += stride) {
+    const int xo = (int)(cv % Wo);
+    const int yo = (int)((cv / Wo) % Ho);
+    const int zo = (int)(cv / ((long long)Wo * Ho));
+    const long long v0 = ((long long)(2 * zo) * H + 2 * yo) * W + 2 * xo;
+    Pack8<T> px[8], pi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // all sixteen loads of the window in flight
+      const long long v = v0 + ((long long)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
+      load8p(raw + ((long long)n * V + v) * C + c0, px[k]);
+      load8p(xin + ((long long)n * V + v) * 8, pi[k]);
+    }
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long long v = v0 + ((long long)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
+      float x[8], in2[8], x2[8], y[8];
+      unpack8(px[k], x);
+      unpack8(pi[k], in2);
+      second_branch<true>(in2, wa, wb, x2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (x[j] - mu[j]) * rs[j];
+        y[j] = xh > 0.f ? xh : xh * slope;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (x2[j] - mu2[j]) * rs2[j];
+        y[j] += xh > 0.f ? xh : xh * slope;
+      }
+      store8(out + ((long long)n * V + v) * C + c0, y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = y[j] > m[j] ? y[j] : m[j];   // (rounded once by the store below, like the values above)
+    }
+    store8(pooled + ((long long)n * Vo + cv) * C + c0, m);
+  }
+}
+
+int launch_cat_fwd_x_pool(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
+                          int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, void* pooled,
+                          Dims d, hipStream_t s) {
+  if (int e = check_c(C)) return e;
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_epilogue_fwd_x_pool: in_channel %d (1 or 2)", in_channel);
+  SEUNET_CHECK(d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0, "cat_epilogue_fwd_x_pool: odd extent");
+  dim3 grid(epi_partials(d) * 4, d.N);
+  SEUNET_LPV_SWITCH(C / 8, {
+    SEUNET_DTYPE_SWITCH(dtype, cat_fwd_pool_kernel<T, LPV><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, (T*)out, (T*)pooled, d.D, d.H, d.W, w2, in_channel));
+  });
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
 // m1 == nullptr: pass A (f64 sums of both branches); otherwise pass B: writes dx (may alias g_out) and one x-branch
 // weight-gradient record per block into xw_partial (see cat_bwd_kernel XW / XR)
 int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,

@@ -358,11 +358,13 @@ struct Exec {
     mark("pack_input");
     if (int e = launch_pack_input(p.d.dtype, x, p.d.in_channel, at(p.feat[T_X0]), p.dims[0], s)) return e;
     bool lvl_written[2][4] = {{false, false, false, false}, {false, false, false, false}};
+    bool pool_done[kNumOps] = {};
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
       const OpRes& r = p.op[i];
       const std::string n = o.name;
       if (o.kind == OP_POOL) {
+        if (pool_done[i]) continue;          // written by the aggregation block's epilogue (below)
         mark("pool_fwd:" + n);
         if (int e = launch_maxpool_fwd(p.d.dtype, at(p.feat[o.src[0]]), p.C[o.src[0]], at(p.feat[o.dst]), p.dims[kT[o.src[0]].level], s)) return e;
       } else if (o.kind == OP_UP) {
@@ -389,7 +391,15 @@ struct Exec {
           if (int e = launch_xbranch_stats(dat(p.xmom), xbranch_moment_slots(p.dims[lv]), w2, r.cout, p.d.in_channel, p.dims[lv].N,
                                            p.dims[lv].vox(), p.d.eps, fat(r.mean2), fat(r.rstd2), s)) return e;
           mark("cat_fwd:" + n);
-          if (int e = launch_cat_fwd_x(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), at(p.feat[o.xsrc]), w2, p.d.in_channel,
+          // the max-pool that consumes this block (ec33 -> pool0, ec63 -> pool1, ec93 -> pool2) is written by the same kernel
+          const bool pool_next = i + 1 < kNumOps && kOps[i + 1].kind == OP_POOL && kOps[i + 1].src[0] == o.dst &&
+                                 getenv("SEUNET_NO_POOL_FUSE") == nullptr;
+          if (pool_next) {
+            if (int e = launch_cat_fwd_x_pool(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), at(p.feat[o.xsrc]), w2, p.d.in_channel,
+                                              fat(r.mean2), fat(r.rstd2), r.cout, p.d.negative_slope, at(p.feat[o.dst]),
+                                              at(p.feat[kOps[i + 1].dst]), p.dims[lv], s)) return e;
+            pool_done[i + 1] = true;
+          } else if (int e = launch_cat_fwd_x(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), at(p.feat[o.xsrc]), w2, p.d.in_channel,
                                        fat(r.mean2), fat(r.rstd2), r.cout, p.d.negative_slope, at(p.feat[o.dst]), p.dims[lv], s)) return e;
         } else {
           if (o.xname) {

@@ -299,6 +299,9 @@ int launch_xbranch_stats(const double* partial, int slots, const float* w2, int 
 int launch_cat_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
                      int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, Dims d,
                      hipStream_t s);
+int launch_cat_fwd_x_pool(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
+                          int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, void* pooled,
+                          Dims d, hipStream_t s);
 int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,
                      const float* w2, int in_channel, const float* mean2, const float* rstd2, int C, float slope,
                      const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, double* stat_partial,
