@@ -18,7 +18,7 @@ torch.manual_seed(0)
 m = A.SE_UNet(2, 1, act_dtype="bf16").cuda().eval()
 x = torch.rand(1, 2, 512, 512, 512, device="cuda")
 A.sliding_window_predict(m, x[:, :, :128, :128, :256], 128, 64, batch=1, return_tensor=True)      # warm-up
-for batch in (4, 1):
+for batch in (16, 4, 1):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = A.sliding_window_predict(m, x, 128, 64, batch=batch, return_tensor=True)     # result stays on the device (what the
     torch.cuda.synchronize(); dt = time.perf_counter() - t0                               # GPU post-processing takes next)

@@ -758,11 +758,11 @@ def test_sliding_window_192x160x128_matches_oracle_and_512_speed(A, orc):
     vol = torch.rand((1, 2, 512, 512, 512), generator=g, device="cuda")
     A.sliding_window_predict(mb, vol[:, :, :128, :128, :256], batch=1, return_tensor=True)      # warm-up
     res = {}
-    for batch, graph in ((4, True), (1, True), (4, False), (1, False)):
+    for batch, graph in ((4, True), (1, True), (4, False), (1, False), (16, False), (None, False)):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         res[batch, graph] = A.sliding_window_predict(mb, vol, batch=batch, return_tensor=True, graph=graph)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"512^3 sliding window, 343 windows, batch {batch}, {'one HIP graph per batch' if graph else 'eager launches'}: "
+        print(f"512^3 sliding window, 343 windows, batch {batch if batch else 'auto = %d' % A.sliding_window.auto_batch(mb, vol.device)}, {'one HIP graph per batch' if graph else 'eager launches'}: "
               f"{dt:.3f} s ({512 ** 3 / dt / 1e6:.0f} M output voxels/s)")
     assert torch.isfinite(res[4, True]).all() and float(res[4, True].min()) > 0.0 and float(res[4, True].max()) < 1.0
     for k in res:
