@@ -169,10 +169,15 @@ int seunet_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
 /* ---- losses: dice_loss / general_union_loss_lib / atr_loss; train.py:51-76 ------------------------------
  * sums[7] (f64, device): see csrc/loss.hip.  The caller forms the loss from the sums (and all-reduces
  * them first under data parallelism), then calls seunet_loss_grad; the upstream gradient is
- * g_scale * (g_scale_dev ? *g_scale_dev : 1) so it can stay on the device. */
+ * g_scale * (g_scale_dev ? *g_scale_dev : 1) so it can stay on the device.
+ * terms: which losses the caller will form (SEUNET_LOSS_DICE | SEUNET_LOSS_GUL | SEUNET_LOSS_ATR; 0 = all): the sums of the
+ * others are left 0 (the general-union term's pow is the expensive part of the pass; a Dice-only step skips it). */
+#define SEUNET_LOSS_DICE 1
+#define SEUNET_LOSS_GUL 2
+#define SEUNET_LOSS_ATR 4
 int seunet_loss_partial_floats(void);
 int seunet_loss_sums(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
-                     long long n, float* partial, double* sums, seunet_stream_t s);
+                     long long n, float* partial, double* sums, int terms, seunet_stream_t s);
 int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
                      long long n, const double* sums, float c_dice, float c_gul, float c_atr, float g_scale,
                      const float* g_scale_dev, float* g_pred, seunet_stream_t s);

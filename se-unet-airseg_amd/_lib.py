@@ -72,7 +72,7 @@ PROTOTYPES = {
     "seunet_head_bwd_tmp_floats": (_sz, [Dims]),
     "seunet_head_bwd": (_i, [_vp, _pp, _i, _vp, _vp, Dims, _vp]),
     "seunet_loss_partial_floats": (_i, []),
-    "seunet_loss_sums": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _vp, _vp, _vp]),
+    "seunet_loss_sums": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _vp, _vp, _i, _vp]),
     "seunet_loss_grad": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     "seunet_cat_xgrad_records": (_i, [Dims]),
     "seunet_xbranch_moment_slots": (_i, [Dims]),

@@ -195,9 +195,10 @@ int seunet_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
 
 int seunet_loss_partial_floats(void) { return loss_partials() * SEUNET_LOSS_NSUMS; }
 int seunet_loss_sums(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
-                     long long n, float* partial, double* sums, seunet_stream_t s) {
+                     long long n, float* partial, double* sums, int terms, seunet_stream_t s) {
   SEUNET_CHECK(pred && target && partial && sums && n >= 1, "loss_sums: bad argument");
-  return launch_loss_sums(pred, apply_sigmoid, target, weight, skel, n, partial, sums, S(s));
+  SEUNET_CHECK(terms >= 0 && terms <= 7, "loss_sums: terms=%d is not a mask of SEUNET_LOSS_DICE | _GUL | _ATR", terms);
+  return launch_loss_sums(pred, apply_sigmoid, target, weight, skel, n, partial, sums, S(s), terms);
 }
 int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
                      long long n, const double* sums, float c_dice, float c_gul, float c_atr, float g_scale,

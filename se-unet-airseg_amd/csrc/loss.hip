@@ -14,18 +14,29 @@ namespace seunet {
 static constexpr int LOSS_BLOCKS = 1024;   // 4 per CU; each thread handles n / (1024 * 256) elements, 4 per load
 int loss_partials() { return LOSS_BLOCKS; }
 
+// TERMS: bit 0 dice (sums 0-2), bit 1 general union (3-4), bit 2 ATR (5-6); sums of terms that are not asked for stay 0.
+// (The pow of the general-union term costs more than everything else together, and a wave pays it as soon as ONE of its 256
+// voxels is foreground: a Dice-only stage-1 step should not.)
+template <int TERMS>
 __device__ __forceinline__ void loss_terms(float p, int apply_sigmoid, float t, float w, float sk, float (&s)[SEUNET_LOSS_NSUMS]) {
   if (apply_sigmoid) p = 1.f / (1.f + expf(-p));
-  s[0] += p * t;
-  s[1] += p;
-  s[2] += t;
-  if (t != 0.f) s[3] += w * powf(p + 1e-4f, 0.7f) * t;   // (the label is sparse: the pow is skipped where it is multiplied by 0)
-  s[4] += w * (0.2f * p + 0.8f * t);
-  const float ps = p * sk;
-  s[5] += w * ps * sk;
-  s[6] += w * (ps + sk);
+  if (TERMS & 1) {
+    s[0] += p * t;
+    s[1] += p;
+    s[2] += t;
+  }
+  if (TERMS & 2) {
+    if (t != 0.f) s[3] += w * powf(p + 1e-4f, 0.7f) * t;   // (the label is sparse: the pow is skipped where it is multiplied by 0)
+    s[4] += w * (0.2f * p + 0.8f * t);
+  }
+  if (TERMS & 4) {
+    const float ps = p * sk;
+    s[5] += w * ps * sk;
+    s[6] += w * (ps + sk);
+  }
 }
 
+template <int TERMS>
 __global__ void __launch_bounds__(256)
 loss_sums_kernel(const float* __restrict__ pred, int apply_sigmoid, const float* __restrict__ target,
                  const float* __restrict__ weight, const float* __restrict__ skel, long long n,
@@ -41,14 +52,14 @@ loss_sums_kernel(const float* __restrict__ pred, int apply_sigmoid, const float*
       const float4 p = reinterpret_cast<const float4*>(pred)[i], t = reinterpret_cast<const float4*>(target)[i];
       const float4 w = weight ? reinterpret_cast<const float4*>(weight)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
       const float4 k = skel ? reinterpret_cast<const float4*>(skel)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      loss_terms(p.x, apply_sigmoid, t.x, w.x, k.x, s);
-      loss_terms(p.y, apply_sigmoid, t.y, w.y, k.y, s);
-      loss_terms(p.z, apply_sigmoid, t.z, w.z, k.z, s);
-      loss_terms(p.w, apply_sigmoid, t.w, w.w, k.w, s);
+      loss_terms<TERMS>(p.x, apply_sigmoid, t.x, w.x, k.x, s);
+      loss_terms<TERMS>(p.y, apply_sigmoid, t.y, w.y, k.y, s);
+      loss_terms<TERMS>(p.z, apply_sigmoid, t.z, w.z, k.z, s);
+      loss_terms<TERMS>(p.w, apply_sigmoid, t.w, w.w, k.w, s);
     }
   } else {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-      loss_terms(pred[i], apply_sigmoid, target[i], weight ? weight[i] : 1.f, skel ? skel[i] : 0.f, s);
+      loss_terms<TERMS>(pred[i], apply_sigmoid, target[i], weight ? weight[i] : 1.f, skel ? skel[i] : 0.f, s);
   }
   __shared__ float red[4][SEUNET_LOSS_NSUMS];
 #pragma unroll
@@ -120,8 +131,15 @@ loss_grad_kernel(const float* __restrict__ pred, int apply_sigmoid, const float*
 }
 
 int launch_loss_sums(const float* pred, int apply_sigmoid, const float* target, const float* weight,
-                     const float* skel, long long n, float* partial, double* sums, hipStream_t s) {
-  loss_sums_kernel<<<LOSS_BLOCKS, 256, 0, s>>>(pred, apply_sigmoid, target, weight, skel, n, partial);
+                     const float* skel, long long n, float* partial, double* sums, hipStream_t s, int terms) {
+  terms &= 7;
+  if (terms == 0) terms = 7;
+  switch (terms) {
+    case 1: loss_sums_kernel<1><<<LOSS_BLOCKS, 256, 0, s>>>(pred, apply_sigmoid, target, weight, skel, n, partial); break;
+    case 2: loss_sums_kernel<2><<<LOSS_BLOCKS, 256, 0, s>>>(pred, apply_sigmoid, target, weight, skel, n, partial); break;
+    case 6: loss_sums_kernel<6><<<LOSS_BLOCKS, 256, 0, s>>>(pred, apply_sigmoid, target, weight, skel, n, partial); break;
+    default: loss_sums_kernel<7><<<LOSS_BLOCKS, 256, 0, s>>>(pred, apply_sigmoid, target, weight, skel, n, partial); break;
+  }
   loss_sums_final_kernel<<<1, 64 * SEUNET_LOSS_NSUMS, 0, s>>>(partial, LOSS_BLOCKS, sums);
   SEUNET_LAUNCH_CHECK();
   return 0;

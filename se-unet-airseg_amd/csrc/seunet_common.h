@@ -354,7 +354,7 @@ size_t head_bwd_tmp_floats(Dims d0);
 int loss_partials();
 int launch_loss_sums(const float* pred, int apply_sigmoid, const float* target,
                      const float* weight, const float* skel, long long n, float* partial,
-                     double* sums, hipStream_t s);
+                     double* sums, hipStream_t s, int terms = 7);
 int launch_loss_grad(const float* pred, int apply_sigmoid, const float* target,
                      const float* weight, const float* skel, long long n, const double* sums,
                      float c_dice, float c_gul, float c_atr, float g_scale,

@@ -26,14 +26,14 @@ def _prep(t: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tenso
     return torch.broadcast_to(t.to(like.device, torch.float32), like.shape).contiguous()
 
 
-def _sums(pred, apply_sigmoid, target, weight, skel, group):
+def _sums(pred, apply_sigmoid, target, weight, skel, group, terms=0):
     lib = _lib.load()
     n = pred.numel()
     with torch.cuda.device(pred.device):    # launch on pred's GPU even when it is not the current device
         partial = torch.empty(lib.seunet_loss_partial_floats(), dtype=torch.float32, device=pred.device)
         sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=pred.device)
         _lib.check(lib.seunet_loss_sums(pred.data_ptr(), int(apply_sigmoid), target.data_ptr(), _lib.ptr(weight), _lib.ptr(skel),
-                                        n, partial.data_ptr(), sums.data_ptr(), _lib.stream_ptr()), "loss_sums")
+                                        n, partial.data_ptr(), sums.data_ptr(), int(terms), _lib.stream_ptr()), "loss_sums")
     if group is not None:
         import torch.distributed as dist
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group if group is not True else None)
@@ -58,7 +58,9 @@ class _RatioLoss(torch.autograd.Function):
             raise RuntimeError("HIP losses need GPU tensors (no CPU fallback; the CPU oracle is oracle/seunet_oracle.py)")
         p = pred.detach().contiguous().float()
         t, w, s = _prep(target, p), _prep(weight, p), _prep(skel, p)
-        sums = _sums(p, apply_sigmoid, t, w, s, group)
+        # only the sums of the losses with a non-zero coefficient are formed (the others stay 0 and are multiplied by 0)
+        terms = (1 if c_dice else 0) | (2 if c_gul else 0) | (4 if c_atr else 0)
+        sums = _sums(p, apply_sigmoid, t, w, s, group, terms)
         ctx.saved = (p, t, w, s, sums)
         ctx.coef = (float(c_dice), float(c_gul), float(c_atr), bool(apply_sigmoid))
         ctx.shape = pred.shape
