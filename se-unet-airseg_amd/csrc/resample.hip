@@ -971,14 +971,34 @@ int launch_head_fwd(const float* const* level_maps, int nlevels, const float* bi
   return 0;
 }
 
-size_t head_bwd_tmp_floats(Dims d0) {
-  // x-pass outputs of the (<= 3) coarse levels (7/8 of a full-resolution map) + one y-pass output (<= 1/4) + bias partials (f64)
-  const size_t v = (size_t)d0.N * d0.vox();
-  return v + v / 4 + 64 + 2 * (((size_t)d0.N * d0.D * d0.H + HB_ROWS - 1) / HB_ROWS + 64);
+// the y- (or z-) passes of all coarse levels of one head in ONE launch: blockIdx.y = job (one per level)
+struct AxisJob { const float* in; float* out; int I, O; long long inner, total; };
+struct AxisJobs { AxisJob j[3]; };
+__global__ void __launch_bounds__(256) up_transpose_axis_multi_kernel(AxisJobs jobs) {
+  const AxisJob jb = jobs.j[blockIdx.y];
+  if (jb.total == 0) return;
+  const float rs = ac_scale(jb.I, jb.O);
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < jb.total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long in_i = idx % jb.inner;
+    const int i = (int)((idx / jb.inner) % jb.I);
+    const long long outer = idx / (jb.inner * jb.I);
+    int lo, hi;
+    ac_range(i, rs, jb.O, lo, hi);
+    float acc = 0.f;
+    for (int o = lo; o <= hi; ++o) {
+      const float w = ac_weight(o, i, rs, jb.I);
+      if (w != 0.f) acc += w * jb.in[(outer * jb.O + o) * jb.inner + in_i];
+    }
+    jb.out[idx] = acc;
+  }
 }
 
-// g_levels[0] is not written (level 0 uses g_pred itself); g_levels[l>=1] receive the transposed
-// interpolation of g_pred; g_bias (optional) receives sum(g_pred).
+size_t head_bwd_tmp_floats(Dims d0) {
+  // x-pass outputs of the (<= 3) coarse levels (7/8 of a full-resolution map) + their y-pass outputs (<= 21/64) + bias partials (f64)
+  const size_t v = (size_t)d0.N * d0.vox();
+  return v + v / 2 + 64 + 2 * (((size_t)d0.N * d0.D * d0.H + HB_ROWS - 1) / HB_ROWS + 64);
+}
 int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, float* tmp, float* g_bias,
                     Dims d0, hipStream_t s) {
   SEUNET_CHECK(nlevels >= 1 && nlevels <= 4, "head: nlevels=%d out of range", nlevels);
@@ -991,19 +1011,34 @@ int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
     if (g_levels[l]) t1[l] = tmp + off;
     off += rows * (d0.W >> l);
   }
-  float* t2 = tmp + (V - V / 8);                              // (>= the sum of the t1 sizes)
-  double* part = reinterpret_cast<double*>(tmp + ((V + V / 4 + 64 + 1) & ~1ll));
+  float* t2[4] = {nullptr, nullptr, nullptr, nullptr};      // y-pass outputs [N][D0][Hl][Wl], after the t1 region (7/8 V)
+  long long off2 = V - V / 8;
+  for (int l = 1; l < nlevels; ++l) {
+    t2[l] = tmp + off2;
+    off2 += (long long)d0.N * d0.D * (d0.H >> l) * (d0.W >> l);
+  }
+  double* part = reinterpret_cast<double*>(tmp + ((V + V / 2 + 64 + 1) & ~1ll));
   const int nblk = (int)((rows + HB_ROWS - 1) / HB_ROWS);
   SEUNET_CHECK(d0.W <= 1024, "head_bwd: W=%d too large", d0.W);
   const size_t lds = ((size_t)4 * d0.W + (size_t)(d0.W - (d0.W >> 3)) * (HB_K + 2)) * sizeof(float);
   head_bwd_x_multi_kernel<<<nblk, 256, lds, s>>>(g_pred, t1[1], t1[2], t1[3], nlevels, d0.W, rows, g_bias ? part : nullptr);
+  // y-pass of every level in one launch, then z-pass of every level in one launch
+  AxisJobs jy{}, jz{};
+  long long max_y = 0, max_z = 0;
+  int njobs = 0;
   for (int l = 1; l < nlevels; ++l) {
     if (!g_levels[l]) continue;
     const int Dl = d0.D >> l, Hl = d0.H >> l, Wl = d0.W >> l;
-    long long tot = (long long)d0.N * d0.D * Hl * Wl;
-    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(t1[l], t2, Hl, d0.H, Wl, tot);
-    tot = (long long)d0.N * Dl * Hl * Wl;
-    up_transpose_axis_kernel<<<grid_for(tot), 256, 0, s>>>(t2, g_levels[l], Dl, d0.D, (long long)Hl * Wl, tot);
+    const long long ty = (long long)d0.N * d0.D * Hl * Wl, tz = (long long)d0.N * Dl * Hl * Wl;
+    jy.j[njobs] = AxisJob{t1[l], t2[l], Hl, d0.H, (long long)Wl, ty};
+    jz.j[njobs] = AxisJob{t2[l], g_levels[l], Dl, d0.D, (long long)Hl * Wl, tz};
+    max_y = ty > max_y ? ty : max_y;
+    max_z = tz > max_z ? tz : max_z;
+    ++njobs;
+  }
+  if (njobs) {
+    up_transpose_axis_multi_kernel<<<dim3((unsigned)grid_for(max_y), (unsigned)njobs), 256, 0, s>>>(jy);
+    up_transpose_axis_multi_kernel<<<dim3((unsigned)grid_for(max_z), (unsigned)njobs), 256, 0, s>>>(jz);
   }
   if (g_bias) sum_stage2_wide_kernel<<<1, 1024, 0, s>>>(part, nblk, g_bias);
   SEUNET_LAUNCH_CHECK();
