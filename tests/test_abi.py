@@ -59,3 +59,33 @@ def test_pure_host_entry_points_without_gpu():
     assert lib.seunet_net_workspace_bytes(C.byref(bad)) == 0 and "n_classes" in _lib.last_error()
     assert lib.seunet_conv_wpack_bytes(_lib.BF16, 27, 64, 32) == 27 * 4 * 32 * 32
     assert lib.seunet_conv3d_wgrad_workspace_bytes(27, 64, 32) > 0
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """include/seunet_hip.h is the boundary a non-Python binding (cgo / JNI / a C host) talks to: it must compile as strict
+    C99 and the library must link from a C program with nothing but the header (no torch, no HIP headers).  The program
+    calls host-only entry points, so this runs without a GPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "se-unet-airseg_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libseunet_hip.so")) or shutil.which("gcc") is None:
+        pytest.skip("needs the built library and gcc")
+    src = tmp_path / "abi_c.c"
+    src.write_text(
+        '#include "seunet_hip.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  seunet_net_desc d = {1, 2, 1, 64, 64, 64, 1, SEUNET_BF16, SEUNET_CONV_MFMA, 0.01f, 1e-5f};\n"
+        '  printf("%d %d %d\\n", seunet_version(), seunet_net_param_count(&d), seunet_net_workspace_bytes(&d) > 0);\n'
+        "  d.n_classes = 3;\n"
+        '  if (seunet_net_workspace_bytes(&d) != 0) return 2;\n'
+        '  printf("%s\\n", seunet_last_error());\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "abi_c"
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                         "-o", str(exe), "-L", lib_dir, "-lseunet_hip", "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, (run.stdout, run.stderr)
+    lines = run.stdout.strip().splitlines()
+    assert lines[0].split()[1:] == ["117", "1"] and "n_classes" in lines[1]
