@@ -261,6 +261,128 @@ upsample2_fwd_tiled_kernel(const T* __restrict__ in, int C, T* __restrict__ out,
   }
 }
 
+// z-marching form of the forward (the one the network uses for C = 32 / 64 / 128).  A block owns two fine rows x XF fine
+// columns (XF * C = 4096) and a run of ZSF fine planes.  Each thread keeps its four (row, column, 8 channels) items'
+// values at two consecutive COARSE planes in registers: walking the coarse planes once, it blends the new plane's four
+// y/x corners from a small LDS image of the coarse rows (double-buffered, one barrier per coarse plane) and emits the
+// fine planes between the two coarse planes as (1 - lz) * previous + lz * current.  Coarse rows are fetched ~2.3 times
+// in all instead of ~9, the y/x blend is done once per coarse plane instead of once per fine plane, and every thread has
+// the same amount of work.
+constexpr int UFM_XC = 68, UFM_ZSF = 16;
+template <typename T>
+__global__ void __launch_bounds__(256)
+upsample2_fwd_march_kernel(const T* __restrict__ in, int C, T* __restrict__ out, int D, int H, int W, int XF) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ufm_raw[];
+  T* tile = reinterpret_cast<T*>(ufm_raw);                     // [2 buffers][3 coarse rows][UFM_XC][C]
+  const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
+  const int xf0 = blockIdx.x * XF;
+  const int nxf = (Wo - xf0 < XF) ? Wo - xf0 : XF;
+  const int yb = blockIdx.y;
+  const int nseg = (Do + UFM_ZSF - 1) / UFM_ZSF;
+  const int seg = blockIdx.z % nseg;
+  const long long n = blockIdx.z / nseg;
+  const int zf_a = seg * UFM_ZSF, zf_b = zf_a + UFM_ZSF < Do ? zf_a + UFM_ZSF : Do;
+  int i0, i1; float lam;
+  // coarse rows / columns under the block
+  int ya0, ya1, yb0, yb1; float lya, lyb;
+  ac_src(2 * yb, ry, H, ya0, ya1, lya);
+  ac_src(2 * yb + 1, ry, H, yb0, yb1, lyb);
+  const int yc0 = ya0, nyc = yb1 - yc0 + 1;                    // <= 3
+  int xc0, xc1, t0;
+  ac_src(xf0, rx, W, xc0, t0, lam);
+  ac_src(xf0 + nxf - 1, rx, W, t0, xc1, lam);
+  const int nxc = xc1 - xc0 + 1;                               // <= UFM_XC
+  const int buf_elems = 3 * UFM_XC * C;
+  // this thread's four items: fine row, fine column, channel group -> four corner offsets in a tile buffer and weights
+  constexpr int NI = 4;
+  int o00[NI], o01[NI], o10[NI], o11[NI];
+  float w00[NI], w01[NI], w10[NI], w11[NI];
+  long long oofs[NI];
+  bool live[NI];
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int item = threadIdx.x + 256 * it;
+    const int g = item % G;
+    const int r = item / G;
+    const int fx = r % XF, fy = r / XF;                        // fy in {0, 1}
+    live[it] = fx < nxf && fy < 2;
+    const int xo = xf0 + (fx < nxf ? fx : 0);
+    int x0, x1; float lx;
+    ac_src(xo, rx, W, x0, x1, lx);
+    const int y0 = fy ? yb0 : ya0, y1 = fy ? yb1 : ya1;
+    const float ly = fy ? lyb : lya;
+    o00[it] = ((y0 - yc0) * UFM_XC + (x0 - xc0)) * C + g * 8;
+    o01[it] = ((y0 - yc0) * UFM_XC + (x1 - xc0)) * C + g * 8;
+    o10[it] = ((y1 - yc0) * UFM_XC + (x0 - xc0)) * C + g * 8;
+    o11[it] = ((y1 - yc0) * UFM_XC + (x1 - xc0)) * C + g * 8;
+    w00[it] = (1.f - ly) * (1.f - lx); w01[it] = (1.f - ly) * lx; w10[it] = ly * (1.f - lx); w11[it] = ly * lx;
+    oofs[it] = (((n * Do) * Ho + (2 * yb + (fy & 1))) * (long long)Wo + xo) * C + g * 8;   // + zo * Ho * Wo * C
+  }
+  const long long oplane = (long long)Ho * Wo * C;
+  // coarse planes the segment needs
+  ac_src(zf_a, rz, D, i0, i1, lam);
+  const int zc_first = i0;
+  ac_src(zf_b - 1, rz, D, i0, i1, lam);
+  const int zc_last = i1;
+  auto stage = [&](int zc, int buf) {          // coarse rows yc0.. of plane zc -> tile[buf]
+    T* tb = tile + buf * buf_elems;
+    for (int item = threadIdx.x; item < nyc * nxc * G; item += 256) {
+      const int g = item % G;
+      const int r = item / G;
+      const int xi = r % nxc, yi = r / nxc;
+      Pack8<T> v;
+      load8p(in + ((((n * D + zc) * H + (yc0 + yi)) * (long long)W + (xc0 + xi)) * C) + g * 8, v);
+      *reinterpret_cast<Pack8<T>*>(tb + (yi * UFM_XC + xi) * C + g * 8) = v;
+    }
+  };
+  float pprev[NI][8], pcur[NI][8];
+#pragma unroll
+  for (int it = 0; it < NI; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pprev[it][j] = pcur[it][j] = 0.f;
+  int zo = zf_a;
+  stage(zc_first, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int zc = zc_first; zc <= zc_last; ++zc) {
+    if (zc < zc_last) stage(zc + 1, buf ^ 1);                 // next coarse plane into the other buffer (read after the barrier)
+    const T* tb = tile + buf * buf_elems;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      float a[8], b[8], c[8], d[8];
+      Pack8<T> k;
+      k = *reinterpret_cast<const Pack8<T>*>(tb + o00[it]); unpack8(k, a);
+      k = *reinterpret_cast<const Pack8<T>*>(tb + o01[it]); unpack8(k, b);
+      k = *reinterpret_cast<const Pack8<T>*>(tb + o10[it]); unpack8(k, c);
+      k = *reinterpret_cast<const Pack8<T>*>(tb + o11[it]); unpack8(k, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pprev[it][j] = pcur[it][j];
+        pcur[it][j] = w00[it] * a[j] + w01[it] * b[j] + w10[it] * c[j] + w11[it] * d[j];
+      }
+    }
+    // fine planes between coarse planes zc - 1 and zc (or clamped onto zc)
+    while (zo < zf_b) {
+      ac_src(zo, rz, D, i0, i1, lam);
+      const bool between = i1 == zc && i0 == zc - 1, on = i0 == zc && i1 == zc;
+      if (!between && !on) break;
+      const float wp = between ? 1.f - lam : 0.f, wc = between ? lam : 1.f;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        if (!live[it]) continue;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = wp * pprev[it][j] + wc * pcur[it][j];
+        store8(out + oofs[it] + zo * oplane, o);
+      }
+      ++zo;
+    }
+    __syncthreads();                                          // the staged plane is complete; this plane's buffer is free
+    buf ^= 1;
+  }
+}
+
 // gather form of the transposed interpolation: one lane per (input voxel, 8 channels)
 template <typename T>
 __global__ void upsample2_bwd_kernel(const T* __restrict__ g_out, int C, T* g_in, int accumulate, int D,
@@ -866,6 +988,21 @@ int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void
 int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims d, hipStream_t s) {
   SEUNET_CHECK(C % 8 == 0, "upsample2: C=%d must be a multiple of 8", C);
   const long long total = (long long)d.N * d.vox() * 8 * (C / 8);
+  if ((C == 32 || C == 64 || C == 128) && d.D >= 2 && d.H >= 2 && d.W >= 2 && getenv("SEUNET_UP_TILED") == nullptr) {
+    const int XF = 4096 / C;                               // fine columns per block: four (row, column, 8-channel) items per thread
+    const int nseg = (2 * d.D + UFM_ZSF - 1) / UFM_ZSF;
+    const size_t lds_m = (size_t)2 * 3 * UFM_XC * C * dtype_size(dtype);   // <= 102 KB except 128 channels in f32 (tiled kernel)
+    if ((long long)d.N * nseg <= 65535 && d.H <= 65535 && lds_m <= 112 * 1024) {
+      static unsigned long long cfg[3] = {0, 0, 0};
+      if (lds_m > 48 * 1024 && dtype >= 0 && dtype < 3 && first_use_on_device(cfg[dtype]))
+        SEUNET_DTYPE_SWITCH(dtype, SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_march_kernel<T>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024)));
+      dim3 grid((unsigned)((2 * d.W + XF - 1) / XF), (unsigned)d.H, (unsigned)(d.N * nseg));
+      SEUNET_DTYPE_SWITCH(dtype, upsample2_fwd_march_kernel<T><<<grid, 256, lds_m, s>>>((const T*)in, C, (T*)out, d.D, d.H, d.W, XF));
+      SEUNET_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const size_t lds = (size_t)4 * UF_XC * C * sizeof(float);
   if (lds <= 144 * 1024 && (long long)d.N * d.D <= 65535 && d.H <= 65535) {   // up to 128 channels
     static unsigned long long configured[3] = {0, 0, 0};
