@@ -372,6 +372,18 @@ class CapturedForward:
             pass
 
 
+def load_reference_checkpoint(model: "SE_UNet", ckpt, strict: bool = False):
+    """Load a checkpoint written by the reference's training loops into this model (train.py:322-324 saves
+    ``model.module.state_dict()``; train.py:194-196 / test.py load with ``strict=False``).  ``ckpt``: a path or an already loaded
+    state_dict.  Keys are the reference's own (same 117 tensors); a ``module.`` prefix -- a checkpoint saved from the
+    ``DataParallel`` wrapper itself -- is stripped.  Returns torch's ``(missing_keys, unexpected_keys)`` record."""
+    sd = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, bytes, os.PathLike)) else ckpt
+    if isinstance(sd, dict) and "state_dict" in sd and all(not torch.is_tensor(v) for v in sd.values() if v is not sd["state_dict"]):
+        sd = sd["state_dict"]
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    return model.load_state_dict(sd, strict=strict)
+
+
 def get_model():
     """reference SE_UNet.py:240-242."""
     net = SE_UNet(in_channel=2)

@@ -161,3 +161,24 @@ def test_postprocess_surface_and_no_cpu_path():
     assert out[3:17, 3:17].min() == 1.0
     with pytest.raises(RuntimeError):                   # CPU tensor: refused, there is no CPU implementation
         A.double_threshold_iteration(torch.zeros(2, 2, 2), 0.5, 0.4)
+
+
+def test_reference_checkpoints_load_unchanged(tmp_path):
+    """train.py:322-324 saves ``model.module.state_dict()``; train.py:194-196 loads with strict=False.  A file written that
+    way from a reference-shaped model (the oracle has the reference's registry) loads into the HIP model, with or without a
+    DataParallel ``module.`` prefix, and a state_dict saved from the HIP model loads back into the reference-shaped one."""
+    import seunet_amd as A
+    o = orc.build_oracle(2, 1, 1, seed=3)
+    path = tmp_path / "SE_UNet_9.pth"
+    torch.save(o.state_dict(), path)
+    m = A.SE_UNet(in_channel=2, n_classes=1)
+    rec = A.load_reference_checkpoint(m, str(path))
+    assert not rec.missing_keys and not rec.unexpected_keys
+    for (k, v), (k2, v2) in zip(m.state_dict().items(), o.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2)
+    m2 = A.SE_UNet(in_channel=2, n_classes=1)
+    rec = A.load_reference_checkpoint(m2, {"module." + k: v for k, v in o.state_dict().items()})
+    assert not rec.missing_keys and not rec.unexpected_keys and torch.equal(m2.dc5.conv1.weight, o.dc5.conv1.weight)
+    o2 = orc.build_oracle(2, 1, 1, seed=4)
+    o2.load_state_dict(m.state_dict(), strict=True)
+    assert torch.equal(o2.ec33.conv1.weight, o.ec33.conv1.weight)
