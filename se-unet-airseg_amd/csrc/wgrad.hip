@@ -115,14 +115,16 @@ wgrad_kernel(WgArgs a) {
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
-  // bf16 operand addressing.  lane -> 8-byte chunk of a 16-voxel x 32-channel operand: 16-lane group grp covers channels
-  // 16*(grp&1).. and voxels 8*(grp>>1)..+3 (second read: +4 voxels = +64 B); lane li supplies voxel li>>2, channels 4*(li&3)..+3
+  // 16-bit operand addressing (ds_read_b64_tr_b16; second read: +4 voxels = +64 B)
   const unsigned char* abase[NT];   // X image: lane offset + this wave's tap ti (1x1x1: + this wave's first row)
   const unsigned char* bbase;       // dY image
   {
+    // 16-bit storage: v_mfma_f32_16x16x32 (K = the 32 voxels of a row; the chip holds a higher clock on this shape than on
+    // 32x32x16).  16-lane group grp = k-group (voxels 8 grp .. 8 grp + 7, second read + 4 voxels); lane
+    // li = 4q + p supplies voxel 8 grp + q, channels 4p .. 4p + 3 of a 16-channel block (block b: + 2 b planes)
     const int grp = lane >> 4, li = lane & 15;
-    const int pl = 2 * (grp & 1) + ((li & 3) >> 1);                       // 16-byte piece (plane)
-    const int vo = 8 * (grp >> 1) + (li >> 2);                            // voxel within the 16-voxel step
+    const int pl = (li & 3) >> 1;                                         // 16-byte piece (plane) inside the 16-channel block
+    const int vo = 8 * grp + (li >> 2);                                   // voxel within the 32-voxel row
     const int sub = (li & 1) * 8;                                         // byte offset inside the piece
     const int wrow = (TAPS == 27) ? 0 : wave;                             // 1x1x1: wave w takes rows w, w + NW, ...
 #pragma unroll
@@ -253,32 +255,37 @@ wgrad_kernel(WgArgs a) {
       // fragments of step s + 2 and the B fragments of the next (row, kk) are requested before the MFMA of step s
       // issues (rotating buffers, compile-time indices), and a step's address is "per-tap base register + immediate".
       typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
       constexpr int ROWS = (TAPS == 27) ? TZ * TY : TZ * TY / NW;    // 1x1x1: the rows are split over the waves
-      constexpr int NRK = ROWS * 2, NSTEP = NRK * NT;
-      auto a_off = [](int rk) constexpr {   // byte offset of (row, kk) inside the X image, relative to the tap base
-        const int ri = rk >> 1, kk = rk & 1;
+      constexpr int NSTEP = ROWS * NT;                               // one step = (row, tap): 2 x 2 MFMAs of 16x16x32
+      auto a_off = [](int ri) constexpr {   // byte offset of a row inside the X image, relative to the tap base
         const int row = (TAPS == 27) ? ri : ri * NW;                 // (1x1x1: + wave, folded into the base)
-        return ((row / TY * HY + row % TY) * HX + kk * 16) * 16;
+        return ((row / TY * HY + row % TY) * HX) * 16;
       };
-      auto b_off = [](int rk) constexpr {
-        const int ri = rk >> 1, kk = rk & 1;
+      auto b_off = [](int ri) constexpr {
         const int row = (TAPS == 27) ? ri : ri * NW;
-        return (row * TX + kk * 16) * 16;
+        return (row * TX) * 16;
       };
-      bf16x4 abuf[3][2], bbuf[2][2];
+      bf16x4 abuf[3][2][2], bbuf[2][2][2];   // [rotating buffer][16-channel block][first / second 4 voxels]
       auto load_a = [&](auto step_c) __attribute__((always_inline)) {
         constexpr int st = decltype(step_c)::value;
         if constexpr (st < NSTEP) {
-          constexpr int ti = st % NT, rk = st / NT;
-          abuf[st % 3][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(abase[ti] + a_off(rk)));
-          abuf[st % 3][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(abase[ti] + a_off(rk) + 64));
+          constexpr int ti = st % NT, ri = st / NT;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            abuf[st % 3][blk][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(abase[ti] + a_off(ri) + blk * 2 * XPL));
+            abuf[st % 3][blk][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(abase[ti] + a_off(ri) + blk * 2 * XPL + 64));
+          }
         }
       };
-      auto load_b = [&](auto rk_c) __attribute__((always_inline)) {
-        constexpr int rk = decltype(rk_c)::value;
-        if constexpr (rk < NRK) {
-          bbuf[rk % 2][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(bbase + b_off(rk)));
-          bbuf[rk % 2][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(bbase + b_off(rk) + 64));
+      auto load_b = [&](auto ri_c) __attribute__((always_inline)) {
+        constexpr int ri = decltype(ri_c)::value;
+        if constexpr (ri < ROWS) {
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            bbuf[ri % 2][blk][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(bbase + b_off(ri) + blk * 2 * YPL));
+            bbuf[ri % 2][blk][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(bbase + b_off(ri) + blk * 2 * YPL + 64));
+          }
         }
       };
       load_b(std::integral_constant<int, 0>{});
@@ -286,17 +293,26 @@ wgrad_kernel(WgArgs a) {
       load_a(std::integral_constant<int, 1>{});
       [&]<int... ST>(std::integer_sequence<int, ST...>) __attribute__((always_inline)) {
         ([&]() __attribute__((always_inline)) {
-          constexpr int ti = ST % NT, rk = ST / NT;
+          constexpr int ti = ST % NT, ri = ST / NT;
           load_a(std::integral_constant<int, ST + 2>{});
-          if constexpr (ti == 0) load_b(std::integral_constant<int, rk + 1>{});
-          __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of this step's MFMA)
-          const bf16x8 afr = __builtin_shufflevector(abuf[ST % 3][0], abuf[ST % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
-          const bf16x8 bfr = __builtin_shufflevector(bbuf[rk % 2][0], bbuf[rk % 2][1], 0, 1, 2, 3, 4, 5, 6, 7);
-          if constexpr (std::is_same<T, f16_t>::value) {   // (the transposing LDS read is type-agnostic: 16-bit patterns)
-            typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr), __builtin_bit_cast(f16x8, bfr), acc[ti], 0, 0, 0);
-          } else {
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[ti], 0, 0, 0);
+          if constexpr (ti == 0) load_b(std::integral_constant<int, ri + 1>{});
+          __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of this step's MFMAs)
+#pragma unroll
+          for (int ab = 0; ab < 2; ++ab) {
+            const bf16x8 afr = __builtin_shufflevector(abuf[ST % 3][ab][0], abuf[ST % 3][ab][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+              const bf16x8 bfr = __builtin_shufflevector(bbuf[ri % 2][bb][0], bbuf[ri % 2][bb][1], 0, 1, 2, 3, 4, 5, 6, 7);
+              const int q = 4 * (2 * ab + bb);           // block (ab, bb) lives in elements q .. q + 3 of acc[ti]
+              f32x4 c = {acc[ti][q], acc[ti][q + 1], acc[ti][q + 2], acc[ti][q + 3]};
+              if constexpr (std::is_same<T, f16_t>::value) {   // (the transposing LDS read is type-agnostic: 16-bit patterns)
+                typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, afr), __builtin_bit_cast(f16x8, bfr), c, 0, 0, 0);
+              } else {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, c, 0, 0, 0);
+              }
+              acc[ti][q] = c[0]; acc[ti][q + 1] = c[1]; acc[ti][q + 2] = c[2]; acc[ti][q + 3] = c[3];
+            }
           }
           __builtin_amdgcn_sched_barrier(0);   // keep the issue order written here
         }(), ...);
@@ -331,8 +347,11 @@ wgrad_kernel(WgArgs a) {
       if (tap < 27) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-          out[(tap * 32 + row) * 32 + col] = acc[ti][r];
+          // f32: 32x32 accumulator (row = ci, col = co).  16-bit: four 16x16 blocks, element r = 4 (2 a + b) + i is
+          // ci = 16 a + 4 (lane >> 4) + i, co = 16 b + (lane & 15)
+          const int row = sizeof(T) == 4 ? (r & 3) + 8 * (r >> 2) + 4 * h : 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3);
+          const int cc = sizeof(T) == 4 ? col : 16 * ((r >> 2) & 1) + (lane & 15);
+          out[(tap * 32 + row) * 32 + cc] = acc[ti][r];
         }
       }
     }
@@ -343,8 +362,9 @@ wgrad_kernel(WgArgs a) {
     float* part = reinterpret_cast<float*>(smem);   // [NW][1024]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      part[wave * 1024 + row * 32 + col] = acc[0][r];
+      const int row = sizeof(T) == 4 ? (r & 3) + 8 * (r >> 2) + 4 * h : 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3);
+      const int cc = sizeof(T) == 4 ? col : 16 * ((r >> 2) & 1) + (lane & 15);
+      part[wave * 1024 + row * 32 + cc] = acc[0][r];
     }
     __syncthreads();
     float* out = a.slab + ((size_t)combo * gridDim.x + blockIdx.x) * 1024;
