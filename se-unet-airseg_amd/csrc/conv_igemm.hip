@@ -648,10 +648,15 @@ __global__ void conv_pack_multi_kernel(PackList l) {
   conv_pack_body<T>(e.w, e.taps, e.cin_w, e.cout_w, e.tflip, reinterpret_cast<T*>(e.out), e.cin_e, e.cout_e, e.nchunks, e.ncol, e.total);
 }
 
-// N columns per workgroup.  64 columns (two MFMA column blocks per A fragment, one workgroup per CU) only pay when
-// the K loop is long; measured on MI355X (scripts/bench_conv.py): 32->64 channel convs run 20-25 % faster as two
-// 32-column workgroups per CU, 128->64 runs 10 % faster with 64 columns.
-static inline int conv_ncol(int cin_e, int cout_e) { return (cout_e > 32 && cin_e >= 64) ? 64 : 32; }
+// N columns per workgroup.  Round 1 chose 64 columns (two MFMA column blocks per A fragment, one workgroup per CU) for
+// >= 64 -> > 32 channel layers (128 -> 64 ran 10 % faster that way).  Since the column blocks of one tile run back to back on
+// one XCD (the second finds the input tile in that L2), two 32-column workgroups per CU win everywhere: dc3 forward 0.47 ->
+// 0.45 ms, data gradient 0.52 -> 0.47 ms, the 128 -> 64 1x1x1 blocks 0.14 -> 0.12 ms, the 16^3-level layers 0.033 -> 0.022 ms
+// (17.53 -> 17.20 ms per step).  SEUNET_CONV_NCOL=64 restores the old rule for A/B timing.
+static inline int conv_ncol(int cin_e, int cout_e) {
+  static const bool wide = [] { const char* e = getenv("SEUNET_CONV_NCOL"); return e && atoi(e) == 64; }();
+  return (wide && cout_e > 32 && cin_e >= 64) ? 64 : 32;
+}
 unsigned long long* g_conv_debug = nullptr;   // set by seunet_debug_set_buffer (diagnostic builds)
 static inline int conv_kc(int dtype) { return dtype_size(dtype) == 2 ? 16 : 8; }
 
