@@ -25,10 +25,19 @@ int epi_partials(Dims d) {
   // One partial record per block and sample.  128 voxels per block at least: the coarse levels (32^3, 16^3) were running
   // pass A on 4..32 blocks per sample, 32 dependent iterations each (36 us for a 16^3 x 64-channel tensor).  256 at most
   // (every record is summed again by the finalize kernels: 512 made those 30 % slower for nothing).
+  // Wave quantisation: pass A of the one-gate blocks holds 3 workgroups per CU (162 VGPRs), i.e. 768 on the chip; 4 x 256 =
+  // 1024 blocks ran as one full round and a third of a second one.  The count per launch (N x partials; the other passes
+  // use 4 x as many) is therefore rounded down to a multiple of 768 once it exceeds it: 4 x 192 at the bench shape, measured
+  // against 96 / 160 / 224 / 256 / 384 per sample (sum of the epilogue classes 5.64 ms vs 6.12 / 5.90 / 5.99 / 5.83 / 5.86).
   long long v = d.vox();
   long long p = v / 128;
   if (p < 1) p = 1;
   if (p > 256) p = 256;
+  const long long n = d.N > 0 ? d.N : 1, round = 3 * 256;
+  if (n * p >= round) {
+    const long long q = (n * p / round) * round / n;
+    if (q >= 1) p = q;
+  }
   return (int)p;
 }
 
