@@ -74,6 +74,20 @@ int seunet_conv3d_stream_pack(int dtype, const float* w, int cin_w, int cout_w, 
                               seunet_stream_t s);
 int seunet_conv3d_stream(int dtype, int dilation, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
                          int dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s);
+/* The same reference op (nn.Conv3d 3x3x3, SE_UNet.py:15,57, with the torch.cat of :222,228 fused) for the 32- and 64-input-channel
+ * layers of the fine levels, forward and data gradient, on the marching kernel (csrc/conv_march.hip): bf16 | f16, one or two
+ * source tensors of equal channel count (32 or 64 channels together), destinations in multiples of 16 channels (32 or more
+ * together; a null destination drops its channels), dilation 1 | 2.  Weights: seunet_conv3d_march_pack (transpose_flip = 1:
+ * data-gradient operator).  bias / stats_partial ([n][seunet_conv3d_march_slots][cout][2] f64) belong to the forward form,
+ * dst_accumulate (+=) to the data-gradient form. */
+int seunet_conv3d_march_supported(int dtype, int dilation, int nsrc, const int* src_c, int ndst, const int* dst_c);
+size_t seunet_conv3d_march_wpack_bytes(int cin, int cout);
+int seunet_conv3d_march_slots(int dilation, int cin, int cout, seunet_dims dims);
+int seunet_conv3d_march_pack(int dtype, const float* w, int cin_w, int cout_w, int transpose_flip, int cin, int cout, void* wpack,
+                             seunet_stream_t s);
+int seunet_conv3d_march(int dtype, int dilation, int nsrc, const void* const* src, const int* src_c, const void* wpack, const float* bias,
+                        int ndst, void* const* dst, const int* dst_c, const int* dst_accumulate, double* stats_partial, seunet_dims dims,
+                        seunet_stream_t s);
 /* weight gradient of the same small-channel layers on the streaming structure (csrc/wgrad_stream.hip): x (x_c = 8 | 16 | 32
  * channels, cin of them carry weights), dy (dy_c channels, cout valid); dw: (cout, cin, 3, 3, 3) f32, overwritten. */
 int seunet_conv3d_wgrad_stream_supported(int dtype, int dilation, int x_c, int dy_c);

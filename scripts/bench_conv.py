@@ -11,7 +11,7 @@ only = sys.argv[1] if len(sys.argv) > 1 else ""
 reps = int(os.environ.get("REPS", 5))
 # name, splits, cout, dil, size
 CASES = [("dc5", [32, 32], 32, 1, 128), ("dc3", [64, 64], 64, 1, 64), ("ec3", [16], 32, 2, 128), ("dc6", [32], 16, 1, 128),
-         ("ec2", [8], 16, 1, 128), ("ec6", [32], 64, 2, 64), ("dc4", [64], 32, 1, 64),
+         ("ec2", [8], 16, 1, 128), ("ec6", [32], 64, 2, 64), ("dc4", [64], 32, 1, 64), ("ec4", [32], 32, 1, 64), ("ec5", [32], 32, 2, 64),
          # 1x1x1 layers (name ends in "_1"): the x33 / ec33 shortcut convolutions
          ("x33_1", [8], 32, 1, 128), ("ec33_1", [32], 32, 1, 128), ("ec63_1", [64], 64, 1, 64)]
 dt = torch.bfloat16
@@ -56,6 +56,26 @@ for name, split, cout, dil, size in CASES:
     def wgrad():
         _lib.check(lib.seunet_conv3d_wgrad(code, 0, TAPS, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, dy.data_ptr(), cout,
                                            dw.data_ptr(), ws.data_ptr(), nb, dims, _lib.stream_ptr()))
+    # the marching kernel (csrc/conv_march.hip) on the same operands, where it serves the shape
+    march = TAPS == 27 and bool(lib.seunet_conv3d_march_supported(code, dil, len(srcs), _lib.int_array(split), 1, _lib.int_array([cout])))
+    march_d = TAPS == 27 and bool(lib.seunet_conv3d_march_supported(code, dil, 1, _lib.int_array([cout]), len(split), _lib.int_array(split)))
+    if march:
+        wm = torch.empty(lib.seunet_conv3d_march_wpack_bytes(cin, cout), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.seunet_conv3d_march_pack(code, w.data_ptr(), cin, cout, 0, cin, cout, wm.data_ptr(), _lib.stream_ptr()))
+        mslots = lib.seunet_conv3d_march_slots(dil, cin, cout, dims)
+        mstats = torch.zeros((B, mslots, cout, 2), dtype=torch.float64, device="cuda")
+        bias = torch.zeros(cout, device="cuda")
+        out_m = torch.empty_like(out)
+    if march_d:
+        wmd = torch.empty(lib.seunet_conv3d_march_wpack_bytes(cout, cin), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.seunet_conv3d_march_pack(code, w.data_ptr(), cin, cout, 1, cout, cin, wmd.data_ptr(), _lib.stream_ptr()))
+        gs_m = [torch.empty_like(s) for s in srcs]
+    def mfwd():
+        _lib.check(lib.seunet_conv3d_march(code, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), wm.data_ptr(), bias.data_ptr(),
+                                           1, _lib.ptr_array([out_m]), _lib.int_array([cout]), _lib.int_array([0]), mstats.data_ptr(), dims, _lib.stream_ptr()))
+    def mdgrad():
+        _lib.check(lib.seunet_conv3d_march(code, dil, 1, _lib.ptr_array([dy]), _lib.int_array([cout]), wmd.data_ptr(), None,
+                                           len(gs_m), _lib.ptr_array(gs_m), _lib.int_array(split), _lib.int_array([0] * len(gs_m)), None, dims, _lib.stream_ptr()))
     which = os.environ.get("WHICH", "fwd,dgrad,wgrad").split(",")
     if os.environ.get("SEUNET_STAMP"):
         import ctypes as C
@@ -83,4 +103,14 @@ for name, split, cout, dil, size in CASES:
         if nm in which:
             ms = timeit(fn)
             res.append("%s %.3f ms %.0f TF/s" % (nm, ms, flops / ms / 1e9))
+    if march and "fwd" in which:
+        fwd(); mfwd(); torch.cuda.synchronize()
+        err = float((out_m.float() - out.float()).abs().max()) / float(out.float().abs().max())
+        ms = timeit(mfwd)
+        res.append("MARCH fwd %.3f ms %.0f TF/s (rel diff %.1e)" % (ms, flops / ms / 1e9, err))
+    if march_d and "dgrad" in which:
+        dgrad(); mdgrad(); torch.cuda.synchronize()
+        err = max(float((a.float() - b.float()).abs().max()) / float(b.float().abs().max()) for a, b in zip(gs_m, gs))
+        ms = timeit(mdgrad)
+        res.append("MARCH dgrad %.3f ms %.0f TF/s (rel diff %.1e)" % (ms, flops / ms / 1e9, err))
     print("%-4s %s->%d d%d @%d^3 B%d: " % (name, split, cout, dil, size, B) + " | ".join(res), flush=True)

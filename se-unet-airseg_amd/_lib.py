@@ -50,6 +50,11 @@ PROTOTYPES = {
     "seunet_conv3d_stream_slots": (_i, [_i, Dims]),
     "seunet_conv3d_stream_pack": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "seunet_conv3d_stream": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, Dims, _vp]),
+    "seunet_conv3d_march_supported": (_i, [_i, _i, _i, _ip, _i, _ip]),
+    "seunet_conv3d_march_wpack_bytes": (_sz, [_i, _i]),
+    "seunet_conv3d_march_slots": (_i, [_i, _i, _i, Dims]),
+    "seunet_conv3d_march_pack": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "seunet_conv3d_march": (_i, [_i, _i, _i, _pp, _ip, _vp, _vp, _i, _pp, _ip, _ip, _vp, Dims, _vp]),
     "seunet_conv3d_wgrad_stream_supported": (_i, [_i, _i, _i, _i]),
     "seunet_conv3d_wgrad_stream_workspace_bytes": (_sz, [_i, _i, _i, Dims]),
     "seunet_conv3d_wgrad_stream": (_i, [_i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, Dims, _vp]),

@@ -85,6 +85,36 @@ int seunet_conv3d_stream(int dtype, int dilation, const void* src, int src_c, co
                          int dst_accumulate, double* stats_partial, seunet_dims dims, seunet_stream_t s) {
   return launch_conv_stream(dtype, dilation, src, src_c, wpack, bias, dst, dst_c, dst_accumulate, stats_partial, D(dims), S(s));
 }
+static int make_dst(int ndst, void* const* dst, const int* dst_c, const int* dst_acc, DstList& dl) {
+  SEUNET_CHECK(ndst >= 1 && ndst <= 3 && dst_c, "bad destination list");
+  dl = DstList{};
+  dl.n = ndst;
+  for (int i = 0; i < ndst; ++i) { dl.ptr[i] = dst ? dst[i] : nullptr; dl.C[i] = dst_c[i]; dl.acc[i] = dst_acc ? dst_acc[i] : 0; }
+  return 0;
+}
+int seunet_conv3d_march_supported(int dtype, int dilation, int nsrc, const int* src_c, int ndst, const int* dst_c) {
+  if (nsrc < 1 || nsrc > 3 || ndst < 1 || ndst > 3 || !src_c || !dst_c) return 0;
+  SrcList sl{}; DstList dl{};
+  sl.n = nsrc; dl.n = ndst;
+  for (int i = 0; i < nsrc; ++i) sl.C[i] = src_c[i];
+  for (int i = 0; i < ndst; ++i) dl.C[i] = dst_c[i];
+  return conv_march_supported(dtype, 27, dilation, sl, dl) ? 1 : 0;
+}
+size_t seunet_conv3d_march_wpack_bytes(int cin, int cout) { return conv_march_wpack_bytes(cin, cout); }
+int seunet_conv3d_march_slots(int dilation, int cin, int cout, seunet_dims dims) { return conv_march_slots(D(dims), dilation, cin, cout); }
+int seunet_conv3d_march_pack(int dtype, const float* w, int cin_w, int cout_w, int transpose_flip, int cin, int cout, void* wpack,
+                             seunet_stream_t s) {
+  return launch_conv_march_pack(dtype, w, cin_w, cout_w, transpose_flip, cin, cout, wpack, S(s));
+}
+int seunet_conv3d_march(int dtype, int dilation, int nsrc, const void* const* src, const int* src_c, const void* wpack, const float* bias,
+                        int ndst, void* const* dst, const int* dst_c, const int* dst_accumulate, double* stats_partial, seunet_dims dims,
+                        seunet_stream_t s) {
+  SrcList sl; DstList dl;
+  if (int e = make_src(nsrc, src, src_c, sl)) return e;
+  SEUNET_CHECK(dst != nullptr, "conv3d_march: null destination list");
+  if (int e = make_dst(ndst, dst, dst_c, dst_accumulate, dl)) return e;
+  return launch_conv_march(dtype, dilation, sl, wpack, bias, dl, stats_partial, D(dims), S(s));
+}
 int seunet_conv3d_wgrad_stream_supported(int dtype, int dilation, int x_c, int dy_c) { return wgrad_stream_supported(dtype, 27, dilation, x_c, dy_c) ? 1 : 0; }
 size_t seunet_conv3d_wgrad_stream_workspace_bytes(int x_c, int dy_c, int dilation, seunet_dims dims) {
   return wgrad_stream_workspace_bytes(x_c, dy_c, dilation, D(dims));

@@ -60,16 +60,20 @@ void prof_mark(const char* tag, hipStream_t s) {
   ++p.used;
 }
 // hipFuncSetAttribute is per device: each kernel instantiation keeps a bit mask of the devices it was configured on
-// (one process per GPU is the normal case; a process driving several devices, e.g. nn.DataParallel, still works)
-bool first_use_on_device(unsigned long long& mask) {
+// (one process per GPU is the normal case; a process driving several devices, e.g. nn.DataParallel, still works).
+// Raise a kernel's dynamic-LDS limit once per (instantiation, device).  The attribute call runs under the lock and the
+// device's bit is set only when it succeeded: a second host thread can neither launch before the limit is in place nor skip
+// a call that failed.
+int configure_kernel_lds(unsigned long long& mask, const void* fn, int bytes) {
   static std::mutex mu;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  SEUNET_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(mu);
-  const unsigned long long bit = 1ull << dev;
-  if (mask & bit) return false;
+  const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+  if (bit && (mask & bit)) return 0;
+  SEUNET_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   mask |= bit;
-  return true;
+  return 0;
 }
 
 // ---- a per-device page of zeros: source of padding voxels / channels for the weight-gradient LDS-DMA -------------

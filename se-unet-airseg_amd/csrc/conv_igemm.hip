@@ -710,10 +710,7 @@ static int launch_one(const ConvKArgs& a, dim3 grid, hipStream_t s) {
   constexpr int LDS_E = 4 * 128 * (32 * NSUB * (int)sizeof(T) + 16);                       // the four waves' store stages
   constexpr int LDS = (LDS_K > LDS_E ? LDS_K : LDS_E) + 4 * 32 * NSUB * 16;                // + the statistics partials
   static unsigned long long configured = 0;   // per instantiation: devices on which the LDS limit was raised
-  if (first_use_on_device(configured)) {
-    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, NSUB, TAPS, DIL>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  }
+  if (int e = configure_kernel_lds(configured, reinterpret_cast<const void*>(&conv_igemm_kernel<T, NSUB, TAPS, DIL>), LDS)) return e;
   conv_igemm_kernel<T, NSUB, TAPS, DIL><<<grid, 256, LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;

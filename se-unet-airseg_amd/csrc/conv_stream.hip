@@ -456,9 +456,7 @@ template <typename T, int CIN, int COUTP, bool XFOLD, int DIL, bool FWD, bool DA
 static int stream_launch_acc(const StreamArgs& a, dim3 grid, hipStream_t s) {
   using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL, DACC>;
   static unsigned long long configured = 0;
-  if (first_use_on_device(configured))
-    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL, FWD, DACC>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
+  if (int e = configure_kernel_lds(configured, reinterpret_cast<const void*>(&conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL, FWD, DACC>), Geo::LDS)) return e;
   conv_stream_kernel<T, CIN, COUTP, XFOLD, DIL, FWD, DACC><<<grid, ST_NW * 64, Geo::LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;

@@ -122,6 +122,11 @@ const OpDesc kOps[] = {
 constexpr int kNumOps = sizeof(kOps) / sizeof(kOps[0]);
 
 inline bool is_input(int t) { return t <= T_X2; }
+// levels on which the marching conv pays: full 32-voxel rows and enough (y, x) patches x planes for one workgroup per CU
+inline bool march_level(const Dims& d) {
+  static const long long minvox = [] { const char* e = getenv("SEUNET_MARCH_MINVOX"); return e ? atoll(e) : 48LL * 48 * 48; }();
+  return d.W >= 32 && d.vox() >= minvox;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // workspace plan
@@ -131,6 +136,7 @@ struct OpRes {
   int cin = 0, cout = 0, taps = 0;
   bool need_dgrad = false;
   bool stream_f = false, stream_d = false, stream_w = false;   // forward / data gradient / weight gradient on the streaming kernels
+  bool march_f = false, march_d = false;                       // forward / data gradient on the marching kernel (conv_march.hip)
 };
 
 struct Plan {
@@ -145,6 +151,7 @@ struct Plan {
   // x-branches (x33 / x63 / x93) recomputed from the <= 2-channel input instead of materialised (csrc/epilogue.hip, XR)
   bool fuse_x = false;
   bool use_stream = true;
+  bool use_march = true;
   size_t wgrad_ws_bytes;
   size_t total;
   int stat_slots_max;
@@ -171,6 +178,7 @@ struct Plan {
     size_t gx_max = 0, wg_max = 0, xw_max = 0, xmom_max = 0;
     fuse_x = d.in_channel <= 2 && d.conv_impl != SEUNET_CONV_NAIVE;
     use_stream = getenv("SEUNET_NO_STREAM") == nullptr;   // (diagnostic switch for A/B timing; the default is on)
+    use_march = getenv("SEUNET_NO_MARCH") == nullptr;     // (likewise)
     int slots_max = 1, cmax = 8;
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
@@ -193,9 +201,28 @@ struct Plan {
       const bool stream_ok = use_stream && o.kind == OP_GATED && o.nsrc == 1 && d.conv_impl != SEUNET_CONV_NAIVE;
       r.stream_f = stream_ok && conv_stream_supported(d.dtype, 27, o.dil, C[o.src[0]], r.cout);
       r.stream_d = stream_ok && r.need_dgrad && conv_stream_supported(d.dtype, 27, o.dil, r.cout, C[o.src[0]]);
-      r.wp_f = take(r.stream_f ? conv_stream_wpack_bytes(C[o.src[0]]) : conv_wpack_bytes(d.dtype, r.taps, r.cin, r.cout));
-      if (r.need_dgrad) r.wp_d = take(r.stream_d ? conv_stream_wpack_bytes(r.cout) : conv_wpack_bytes(d.dtype, r.taps, r.cout, r.cin));
+      // 32 / 64-input-channel 3x3x3 layers of the levels that fill the chip with 32-voxel rows run on the marching kernel
+      // (one workgroup per CU, weights in registers): dc5, dc4, ec4..ec6 and the data gradients of those and of dc3
+      if (use_march && o.kind == OP_GATED && d.conv_impl != SEUNET_CONV_NAIVE && !r.stream_f && march_level(dims[lv])) {
+        SrcList sl{}; DstList dl{};
+        sl.n = o.nsrc;
+        for (int k = 0; k < o.nsrc; ++k) sl.C[k] = C[o.src[k]];
+        dl.n = 1; dl.C[0] = r.cout;
+        r.march_f = conv_march_supported(d.dtype, 27, o.dil, sl, dl);
+        if (r.need_dgrad && !r.stream_d) {
+          SrcList gs{}; DstList gd{};
+          gs.n = 1; gs.C[0] = r.cout;
+          gd.n = o.nsrc;
+          for (int k = 0; k < o.nsrc; ++k) gd.C[k] = C[o.src[k]];
+          r.march_d = conv_march_supported(d.dtype, 27, o.dil, gs, gd);
+        }
+      }
+      r.wp_f = take(r.stream_f ? conv_stream_wpack_bytes(C[o.src[0]])
+                               : (r.march_f ? conv_march_wpack_bytes(cin, r.cout) : conv_wpack_bytes(d.dtype, r.taps, r.cin, r.cout)));
+      if (r.need_dgrad) r.wp_d = take(r.stream_d ? conv_stream_wpack_bytes(r.cout)
+                                                 : (r.march_d ? conv_march_wpack_bytes(r.cout, cin) : conv_wpack_bytes(d.dtype, r.taps, r.cout, r.cin)));
       if (r.stream_f) slots_max = std::max(slots_max, conv_stream_slots(dims[lv], o.dil));
+      if (r.march_f) slots_max = std::max(slots_max, conv_march_slots(dims[lv], o.dil, cin, r.cout));
       r.stream_w = stream_ok && wgrad_stream_supported(d.dtype, 27, o.dil, C[o.src[0]], r.cout);
       if (r.stream_w) wg_max = std::max(wg_max, wgrad_stream_workspace_bytes(C[o.src[0]], r.cout, o.dil, dims[lv]));
       wg_max = std::max(wg_max, wgrad_workspace_bytes(r.taps, r.cin, r.cout));
@@ -280,11 +307,15 @@ struct Exec {
 
   // conv (+ InstanceNorm statistics) of one block: raw <- conv(src), (mean, rstd) <- stats(raw)
   int conv_and_stats(const std::string& nm, int taps, int dil, const SrcList& src, int cin, const float* w, const float* bias, size_t wp_off,
-                     size_t raw_off, int cout, size_t mean_off, size_t rstd_off, const Dims& dm, bool stream = false) {
+                     size_t raw_off, int cout, size_t mean_off, size_t rstd_off, const Dims& dm, bool stream = false, bool march = false) {
     DstList dst{};
     dst.n = 1; dst.ptr[0] = at(raw_off); dst.C[0] = cout; dst.acc[0] = 0;
     int slots;
-    if (stream) {
+    if (march) {
+      mark("conv_fwd:" + nm);   // (weights were packed by pack_all_weights)
+      if (int e = launch_conv_march(p.d.dtype, dil, src, at(wp_off), bias, dst, dat(p.stats), dm, s)) return e;
+      slots = conv_march_slots(dm, dil, src.total(), cout);
+    } else if (stream) {
       mark("conv_fwd:" + nm);   // (weights were packed by pack_all_weights)
       if (int e = launch_conv_stream(p.d.dtype, dil, src.ptr[0], src.C[0], at(wp_off), bias, at(raw_off), cout, 0, dat(p.stats), dm, s)) return e;
       slots = conv_stream_slots(dm, dil);
@@ -343,6 +374,13 @@ struct Exec {
                                             at(dgrad ? r.wp_d : r.wp_f), s)) return e;
         continue;
       }
+      if ((!dgrad && r.march_f) || (dgrad && r.march_d)) {
+        int ctot = 0;
+        for (int k = 0; k < o.nsrc; ++k) ctot += p.C[o.src[k]];
+        if (int e = launch_conv_march_pack(p.d.dtype, P(n + ".conv1.weight"), r.cin, r.cout, dgrad ? 1 : 0, dgrad ? r.cout : ctot,
+                                           dgrad ? ctot : r.cout, at(dgrad ? r.wp_d : r.wp_f), s)) return e;
+        continue;
+      }
       if (!dgrad) {
         jobs.push_back({P(n + ".conv1.weight"), at(r.wp_f), r.taps, r.cin, r.cout, 0});
         if (o.kind == OP_CAT && o.xname && !p.fuse_x) jobs.push_back({P(std::string(o.xname) + ".conv1.weight"), at(r.wp_x), 1, p.d.in_channel, r.cout, 0});
@@ -373,7 +411,7 @@ struct Exec {
       } else if (o.kind == OP_GATED) {
         const int lv = kT[o.dst].level;
         if (int e = conv_and_stats(n, 27, o.dil, srcs(o), r.cin, P(n + ".conv1.weight"), P(n + ".conv1.bias"), r.wp_f, r.raw,
-                                   r.cout, r.mean, r.rstd, p.dims[lv], r.stream_f)) return e;
+                                   r.cout, r.mean, r.rstd, p.dims[lv], r.stream_f, r.march_f)) return e;
         const SseHead hd = sse_head(o, drop1, drop2, !lvl_written[o.head][lv]);
         lvl_written[o.head][lv] = true;
         mark("epi_fwd:" + n);
@@ -460,6 +498,7 @@ struct Exec {
     if (r.stream_d)
       return launch_conv_stream(p.d.dtype, o.dil, at(p.grad[o.dst]), r.cout, at(r.wp_d), nullptr, gd.ptr[0], gd.C[0], gd.acc[0], nullptr,
                                 p.dims[lv], s);
+    if (r.march_d) return launch_conv_march(p.d.dtype, o.dil, gsrc, at(r.wp_d), nullptr, gd, nullptr, p.dims[lv], s);
     if (p.d.conv_impl == SEUNET_CONV_NAIVE)
       return launch_conv_naive(p.d.dtype, r.taps, o.dil, gsrc, r.cout, w, 1, nullptr, gd, p.dims[lv], s);
     return launch_conv_igemm(p.d.dtype, r.taps, o.dil, gsrc, r.cout, at(r.wp_d), nullptr, gd, nullptr, p.dims[lv], s);

@@ -994,9 +994,8 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims d, hi
     const size_t lds_m = (size_t)2 * 3 * UFM_XC * C * dtype_size(dtype);   // <= 102 KB except 128 channels in f32 (tiled kernel)
     if ((long long)d.N * nseg <= 65535 && d.H <= 65535 && lds_m <= 112 * 1024) {
       static unsigned long long cfg[3] = {0, 0, 0};
-      if (lds_m > 48 * 1024 && dtype >= 0 && dtype < 3 && first_use_on_device(cfg[dtype]))
-        SEUNET_DTYPE_SWITCH(dtype, SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_march_kernel<T>),
-                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024)));
+      if (lds_m > 48 * 1024 && dtype >= 0 && dtype < 3)
+        SEUNET_DTYPE_SWITCH(dtype, if (int e = configure_kernel_lds(cfg[dtype], reinterpret_cast<const void*>(&upsample2_fwd_march_kernel<T>), 112 * 1024)) return e);
       dim3 grid((unsigned)((2 * d.W + XF - 1) / XF), (unsigned)d.H, (unsigned)(d.N * nseg));
       SEUNET_DTYPE_SWITCH(dtype, upsample2_fwd_march_kernel<T><<<grid, 256, lds_m, s>>>((const T*)in, C, (T*)out, d.D, d.H, d.W, XF));
       SEUNET_LAUNCH_CHECK();
@@ -1006,9 +1005,8 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims d, hi
   const size_t lds = (size_t)4 * UF_XC * C * sizeof(float);
   if (lds <= 144 * 1024 && (long long)d.N * d.D <= 65535 && d.H <= 65535) {   // up to 128 channels
     static unsigned long long configured[3] = {0, 0, 0};
-    if (lds > 48 * 1024 && dtype >= 0 && dtype < 3 && first_use_on_device(configured[dtype]))
-      SEUNET_DTYPE_SWITCH(dtype, SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample2_fwd_tiled_kernel<T>),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)));
+    if (lds > 48 * 1024 && dtype >= 0 && dtype < 3)
+      SEUNET_DTYPE_SWITCH(dtype, if (int e = configure_kernel_lds(configured[dtype], reinterpret_cast<const void*>(&upsample2_fwd_tiled_kernel<T>), 144 * 1024)) return e);
     dim3 grid((unsigned)((2 * d.W + UF_XF - 1) / UF_XF), (unsigned)d.H, (unsigned)((long long)d.N * d.D));
     SEUNET_DTYPE_SWITCH(dtype, upsample2_fwd_tiled_kernel<T><<<grid, 256, lds, s>>>((const T*)in, C, (T*)out, d.D, d.H, d.W));
     SEUNET_LAUNCH_CHECK();
@@ -1029,8 +1027,7 @@ template <typename T, int TY>
 static int upsample2_bwd_march(const void* g_out, int C, void* g_in, int accumulate, Dims d, int ZS, hipStream_t s) {
   const size_t lds = (size_t)2 * 128 * UM_XF * sizeof(float);   // 40 KB: four workgroups per CU
   static unsigned long long cfg = 0;
-  if (first_use_on_device(cfg))
-    SEUNET_HIP(hipFuncSetAttribute((const void*)upsample2_bwd_march_kernel<T, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (int e = configure_kernel_lds(cfg, (const void*)upsample2_bwd_march_kernel<T, TY>, (int)lds)) return e;
   const int nseg = (d.D + ZS - 1) / ZS;
   dim3 grid((unsigned)((d.W + UM_TX - 1) / UM_TX), (unsigned)((d.H + TY - 1) / TY), (unsigned)(d.N * nseg));
   upsample2_bwd_march_kernel<T, TY><<<grid, 256, lds, s>>>((const T*)g_out, C, (T*)g_in, accumulate, d.D, d.H, d.W, ZS);

@@ -94,9 +94,18 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }   // v_cvt_f16_f32: RNE, overflow -> inf
 // two 16-bit elements <-> one dword, for either 16-bit storage type
 template <typename T> __device__ __forceinline__ unsigned int pack2(float lo, float hi);
-template <> __device__ __forceinline__ unsigned int pack2<bf16_t>(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+// (one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 with two sources: RNE, NaN stays NaN; the scalar casts compiled to two
+// conversions, a shift and an or per dword)
+typedef float seunet_f32x2 __attribute__((ext_vector_type(2)));
+typedef bf16_t seunet_bf16x2 __attribute__((ext_vector_type(2)));
+typedef f16_t seunet_f16x2 __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ unsigned int pack2<bf16_t>(float lo, float hi) {
+  const seunet_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, seunet_bf16x2));
+}
 template <> __device__ __forceinline__ unsigned int pack2<f16_t>(float lo, float hi) {
-  return (unsigned int)__builtin_bit_cast(unsigned short, (f16_t)lo) | ((unsigned int)__builtin_bit_cast(unsigned short, (f16_t)hi) << 16);
+  const seunet_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, seunet_f16x2));
 }
 template <typename T> __device__ __forceinline__ float unpack_lo(unsigned int u);
 template <typename T> __device__ __forceinline__ float unpack_hi(unsigned int u);
@@ -134,10 +143,7 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
   uint4 u;
-  u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-  u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-  u.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
-  u.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+  u.x = pack2<bf16_t>(v[0], v[1]); u.y = pack2<bf16_t>(v[2], v[3]); u.z = pack2<bf16_t>(v[4], v[5]); u.w = pack2<bf16_t>(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = u;
 }
 
@@ -226,6 +232,15 @@ int conv_stream_slots(Dims d, int dil);
 int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int src_c, int dst_c, void* wpack, hipStream_t s);
 int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
                        int dst_accumulate, double* stats, Dims d, hipStream_t s);
+
+// marching 3x3x3 convolution for 32 / 64 source channels (conv_march.hip): bf16 | f16, one or two equal sources, destinations
+// in multiples of 16 channels; forward (bias, statistics) and data gradient (optionally accumulating)
+bool conv_march_supported(int dtype, int taps, int dil, const SrcList& src, const DstList& dst);
+size_t conv_march_wpack_bytes(int cin_e, int cout_e);
+int conv_march_slots(Dims d, int dil, int cin_e, int cout_e);
+int launch_conv_march_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int cin_e, int cout_e, void* wpack, hipStream_t s);
+int launch_conv_march(int dtype, int dil, const SrcList& src, const void* wpack, const float* bias, const DstList& dst, double* stats,
+                      Dims d, hipStream_t s);
 
 // streaming small-channel weight gradient (wgrad_stream.hip)
 bool wgrad_stream_supported(int dtype, int taps, int dil, int x_c, int dy_c);
@@ -339,7 +354,8 @@ int launch_dti(const double* pred, int h, int w, int z, double h_thresh, double 
 int launch_adamw(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const long long* counts, int n, double lr, double beta1, double beta2, double eps, double weight_decay,
                  int step, int maximize, hipStream_t s);
-bool first_use_on_device(unsigned long long& mask);   // true once per (kernel instantiation, device): raises its LDS limit then
+// raises a kernel's dynamic-LDS limit once per (instantiation, device): under a lock, the device's bit is set on success only
+int configure_kernel_lds(unsigned long long& mask, const void* fn, int bytes);
 const void* device_zero_page();   // >= 256 zero bytes on the current device (allocated once per device, never freed)
 int launch_side_upsample(const float* side, int C, int scale, float* out_ncdhw, int c_total,
                          int c_off, Dims dlow, hipStream_t s);

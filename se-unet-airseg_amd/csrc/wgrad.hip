@@ -441,10 +441,7 @@ static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
   constexpr int NVH = (TZ + 2 * HALO) * (TY + 2 * HALO) * (32 + 2 * HALO), NVT = TZ * TY * 32;
   constexpr int LDS = PPV * ((((NVH + 63) / 64) * 64 + 4) + (((NVT + 63) / 64) * 64 + 4)) * 16 + NW * 64 * 32;   // + packed halo coordinates
   static unsigned long long configured = 0;   // per instantiation: devices on which the LDS limit was raised
-  if (first_use_on_device(configured)) {
-    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL, NW>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  }
+  if (int e = configure_kernel_lds(configured, reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, DIL, NW>), LDS)) return e;
   wgrad_kernel<T, TAPS, DIL, NW><<<grid, NW * 64, LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;

@@ -325,9 +325,7 @@ static int ws_launch_t(const WsArgs& a, dim3 grid, hipStream_t s) {
   using Geo = WsGeo<CIN, COUT, DIL>;
   static_assert(Geo::LDS <= 160 * 1024, "wgrad_stream: LDS budget");
   static unsigned long long configured = 0;
-  if (first_use_on_device(configured))
-    SEUNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel<T, CIN, COUT, DIL>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
+  if (int e = configure_kernel_lds(configured, reinterpret_cast<const void*>(&wgrad_stream_kernel<T, CIN, COUT, DIL>), Geo::LDS)) return e;
   wgrad_stream_kernel<T, CIN, COUT, DIL><<<grid, WS_NW * 64, Geo::LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;

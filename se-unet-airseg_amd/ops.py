@@ -131,6 +131,51 @@ def conv3d_stream(src: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     return dst, stats, slots
 
 
+def conv3d_march_supported(srcs: Sequence[torch.Tensor], dst_channels: Sequence[int], dilation: int = 1) -> bool:
+    return bool(_lib.load().seunet_conv3d_march_supported(_code(srcs[0]), dilation, len(srcs), _lib.int_array([t.shape[4] for t in srcs]),
+                                                          len(dst_channels), _lib.int_array(list(dst_channels))))
+
+
+def conv3d_march(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1,
+                 transpose_flip: bool = False, dsts: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                 dst_channels: Optional[Sequence[int]] = None, accumulate: Optional[Sequence[int]] = None, want_stats: bool = False):
+    """The marching 3x3x3 convolution (csrc/conv_march.hip): 32 or 64 source channels (one or two tensors), bf16 / fp16.
+    Returns (list of destination tensors, stats_partial or None, slots)."""
+    lib = _lib.load()
+    code, dims = _code(srcs[0]), _dims_cl(srcs[0])
+    co_w, ci_w = weight.shape[0], weight.shape[1]
+    cout_e = ci_w if transpose_flip else co_w
+    cin = sum(t.shape[4] for t in srcs)
+    if dsts is None:
+        dst_channels = list(dst_channels or [cout_e])
+        dsts = [torch.empty(tuple(srcs[0].shape[:4]) + (c,), dtype=srcs[0].dtype, device=srcs[0].device) for c in dst_channels]
+        accumulate = [0] * len(dsts)
+    else:
+        dst_channels = list(dst_channels or [t.shape[4] for t in dsts])
+        accumulate = list(accumulate or [0] * len(dsts))
+    if not conv3d_march_supported(srcs, dst_channels, dilation):
+        raise RuntimeError(f"conv3d_march: {[t.shape[4] for t in srcs]} -> {dst_channels} channels, dilation {dilation}, "
+                           f"dtype {srcs[0].dtype} is not served by this kernel")
+    cout = sum(dst_channels)
+    wbuf = torch.empty(lib.seunet_conv3d_march_wpack_bytes(cin, cout), dtype=torch.uint8, device=srcs[0].device)
+    w = weight.contiguous().float()
+    _lib.check(lib.seunet_conv3d_march_pack(code, w.data_ptr(), ci_w, co_w, int(transpose_flip), cin, cout, wbuf.data_ptr(), _s()),
+               "conv3d_march_pack")
+    stats, slots = None, 0
+    if want_stats:
+        slots = lib.seunet_conv3d_march_slots(dilation, cin, cout, dims)
+        stats = torch.zeros((dims.n, slots, cout, 2), dtype=torch.float64, device=srcs[0].device)
+    b = None
+    if bias is not None:
+        b = torch.zeros(cout, dtype=torch.float32, device=srcs[0].device)
+        b[:bias.numel()] = bias.float()
+    _lib.check(lib.seunet_conv3d_march(code, dilation, len(srcs), _lib.ptr_array(list(srcs)), _lib.int_array([t.shape[4] for t in srcs]),
+                                       wbuf.data_ptr(), _lib.ptr(b), len(dsts), _lib.ptr_array(list(dsts)),
+                                       _lib.int_array(dst_channels), _lib.int_array(accumulate), _lib.ptr(stats), dims, _s()),
+               "conv3d_march")
+    return list(dsts), stats, slots
+
+
 def conv3d_wgrad(srcs: Sequence[torch.Tensor], dy: torch.Tensor, cin: int, cout: int, taps: int, dilation: int = 1,
                  impl: int = _lib.CONV_MFMA) -> torch.Tensor:
     lib = _lib.load()

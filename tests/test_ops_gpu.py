@@ -467,6 +467,94 @@ def test_conv_stream_weight_gradient(S, case, shape):
     assert float((got - ref2).abs().max()) <= 2e-3 * float(wt.grad.abs().max()) + 1e-4
 
 
+# ---- marching convolution (csrc/conv_march.hip): the 32 / 64-input-channel layers of the fine levels ----
+MARCH_FWD = [  # (source channel split, cout, dilation)
+    ([32, 32], 32, 1),   # dc5 (fused cat): 2 K-steps, 2 N groups x 2 row groups
+    ([64], 32, 1),       # dc4
+    ([32], 32, 1),       # ec4
+    ([32], 32, 2),       # ec5
+    ([32], 64, 2),       # ec6: 4 N groups, 8 rows per wave
+    ([32], 64, 1),
+    ([64], 64, 1),       # ec7 / dc2 shape
+    ([64], 64, 2),       # ec8 / ec9 shape
+    ([64], 32, 2),
+    ([32, 32], 128, 1),  # two N blocks
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 6, 9, 40), (1, 13, 16, 32), (1, 5, 8, 31), (1, 41, 8, 64)])
+@pytest.mark.parametrize("case", MARCH_FWD)
+def test_conv_march_forward_and_stats(S, case, shape, dtype):
+    """Forward + InstanceNorm partial sums against F.conv3d on rounded operands; ragged patches (y, x not multiples of the
+    patch), marches split into segments (41 planes on few workgroups), both z-parity classes of dilation 2, fused
+    concatenation of two sources, several N blocks."""
+    split, cout, dil = case
+    n, d, h, w = shape
+    cin = sum(split)
+    x = rnd(dtype, gen(n, cin, d, h, w, seed=2))
+    wt = rnd(dtype, gen(cout, cin, 3, 3, 3, seed=3, scale=(27 * cin) ** -0.5))
+    b = gen(cout, seed=4, scale=0.1)
+    ref = F.conv3d(x, wt, b, padding=dil, dilation=dil)
+    srcs, o = [], 0
+    for c in split:
+        srcs.append(S.to_cl(x[:, o:o + c].cuda(), dtype))
+        o += c
+    (raw,), part, slots = S.conv3d_march(srcs, wt.cuda(), b.cuda(), dil, want_stats=True)
+    got = S.from_cl(raw, cout)
+    assert_close(got, ref, dtype, "conv_march")
+    mean, rstd = S.stats_finalize(part, slots, d * h * w)
+    rm, rv = ref.mean(dim=(2, 3, 4)), ref.var(dim=(2, 3, 4), unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), rm.numpy(), atol=3e-3)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (rv + 1e-5).rsqrt().numpy(), rtol=2e-2)
+    # the same numbers as the tiled implicit-GEMM kernel to rounding of the stored tensor
+    (raw2,), _, _ = S.conv3d(srcs, wt.cuda(), b.cuda(), dil, 0)
+    assert float((S.from_cl(raw2, cout) - got).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("acc", [[0, 0], [1, 0], [1, 1]])
+@pytest.mark.parametrize("case", [(32, [32, 32], 1),   # dc5: dy 32 -> dx 32 + 32 (two destinations)
+                                  (32, [64], 1),       # dc4
+                                  (64, [32], 2),       # ec6
+                                  (32, [32], 2),       # ec5
+                                  (32, [32], 1),       # ec4
+                                  (64, [64, 64], 1),   # dc3: two N blocks, one per destination
+                                  (64, [64], 2)])      # ec8 / ec9 shape
+def test_conv_march_data_gradient(S, case, acc, dtype):
+    """dgrad: the forward weight (cout = dy channels, cin = dx channels) applied transposed / mirrored, split over the
+    concatenated inputs, each destination optionally += into an existing gradient."""
+    dyc, split, dil = case
+    acc = acc[:len(split)]
+    n, d, h, w = 2, 7, 10, 36
+    dxc = sum(split)
+    wt = rnd(dtype, gen(dyc, dxc, 3, 3, 3, seed=5, scale=(27 * dxc) ** -0.5))
+    dy = rnd(dtype, gen(n, dyc, d, h, w, seed=6))
+    xx = torch.zeros(n, dxc, d, h, w, requires_grad=True)
+    F.conv3d(xx, wt, padding=dil, dilation=dil).backward(dy)
+    ref = xx.grad
+    olds = [rnd(dtype, gen(n, c, d, h, w, seed=7 + i)) for i, c in enumerate(split)]
+    dsts = [S.to_cl(o.cuda(), dtype) for o in olds]
+    got, _, _ = S.conv3d_march([S.to_cl(dy.cuda(), dtype)], wt.cuda(), None, dil, transpose_flip=True, dsts=dsts, accumulate=acc)
+    o = 0
+    for i, c in enumerate(split):
+        want = ref[:, o:o + c] + (olds[i] if acc[i] else 0)
+        assert_close(S.from_cl(got[i], c), want, dtype, f"conv_march dgrad dst {i}")
+        o += c
+
+
+def test_conv_march_dropped_destination_and_long_march(S):
+    """A null destination drops its channels (data gradient towards the network input side); 70 planes in one march."""
+    n, d, h, w = 1, 70, 8, 32
+    wt = rnd("bf16", gen(32, 64, 3, 3, 3, seed=11, scale=(27 * 64) ** -0.5))
+    dy = rnd("bf16", gen(n, 32, d, h, w, seed=12))
+    xx = torch.zeros(n, 64, d, h, w, requires_grad=True)
+    F.conv3d(xx, wt, padding=1).backward(dy)
+    d1 = torch.full((n, d, h, w, 32), 7.0, dtype=torch.bfloat16, device="cuda")
+    got, _, _ = S.conv3d_march([S.to_cl(dy.cuda(), "bf16")], wt.cuda(), None, 1, transpose_flip=True, dsts=[None, d1], dst_channels=[32, 32])
+    assert_close(S.from_cl(got[1], 32), xx.grad[:, 32:], "bf16", "conv_march dropped dst")
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(1, 32, 5, 7, 70), (2, 64, 3, 4, 33), (1, 8, 1, 1, 2), (1, 16, 2, 9, 64), (1, 128, 2, 3, 5),
                                    (2, 64, 9, 4, 33), (1, 128, 4, 6, 20), (1, 32, 40, 9, 17), (1, 32, 33, 16, 16), (1, 64, 4, 4, 4)])
