@@ -21,7 +21,9 @@ device-agnostic ``DropLayer`` with the reference's CPU-generator RNG order (Q6).
 fp16 storage (BASELINE configs[4]) needs what the reference never had: the Dice gradients at initialisation are ~1e-8
 per voxel, below half precision's normal range, so the activation gradients are carried multiplied by a STATIC
 ``loss_scale`` (default 65536 for fp16, 1 otherwise; a build-side extension, attribute ``model.loss_scale``): the incoming
-logit gradients are multiplied by it, the parameter gradients divided by it, nothing else changes.
+logit gradients are multiplied by it, the parameter gradients divided by it, nothing else changes.  A backward pass whose
+scaled gradients overflow (inf / NaN in the flat gradient buffer) yields zero gradients and increments the device counter
+``model.overflow_steps`` (no host synchronisation; lower ``model.loss_scale`` when it is ever non-zero).
 """
 from __future__ import annotations
 
@@ -171,6 +173,7 @@ class _SEUNetFunction(torch.autograd.Function):
         ctx.plist, ctx.drop = plist, (drop1, drop2)
         ctx.dead = meta["dead"]
         ctx.loss_scale = float(meta.get("loss_scale", 1.0))
+        ctx.overflow = meta.get("overflow")
         return pred0, pred1
 
     @staticmethod
@@ -195,7 +198,13 @@ class _SEUNetFunction(torch.autograd.Function):
                                                _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
                                                ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr()), "net_backward")
             if ctx.loss_scale != 1.0:
-                flat.mul_(1.0 / ctx.loss_scale)
+                # a scaled activation gradient beyond half precision's range turns into inf / NaN in the flat buffer: such a step
+                # is dropped (zero gradients) and counted on the device, with no host synchronisation -- the caller reads
+                # ``model.overflow_steps`` when it wants to (and lowers ``model.loss_scale`` if it ever becomes non-zero)
+                ok = torch.isfinite(flat).all()
+                flat.copy_(torch.where(ok, flat * (1.0 / ctx.loss_scale), torch.zeros((), dtype=flat.dtype, device=dev)))
+                if ctx.overflow is not None:
+                    ctx.overflow.add_((~ok).to(ctx.overflow.dtype))
         ctx.ws = None
         return (None, None, None, None) + tuple(grads)
 
@@ -211,6 +220,7 @@ class SE_UNet(nn.Module):
         self.act_dtype = act_dtype or _default_dtype()
         self.conv_impl = _default_conv_impl() if conv_impl is None else conv_impl
         self.loss_scale = 65536.0 if _lib.dtype_code(self.act_dtype) == _lib.F16 else 1.0
+        self.overflow_steps = None    # device counter of backward passes dropped because a scaled gradient left half precision's range
         self.batchnorm, self.bias, self.out_channel2, self.sigmoid_output = False, True, 2, 0
         m = width_mult
         # registration order == reference SE_UNet.py:108-153 (state_dict / parameters() order)
@@ -284,6 +294,10 @@ class SE_UNet(nn.Module):
         meta = {"in_channel": self.in_channel, "n_classes": self.n_classes, "width_mult": self.width_mult,
                 "dtype": _lib.dtype_code(self.act_dtype), "conv_impl": self.conv_impl,
                 "negative_slope": float(self.negative_slope), "dead": self._dead, "loss_scale": float(self.loss_scale)}
+        if self.loss_scale != 1.0:
+            if self.overflow_steps is None or self.overflow_steps.device != x.device:
+                self.overflow_steps = torch.zeros((), dtype=torch.int64, device=x.device)
+            meta["overflow"] = self.overflow_steps
         if not self._registry_checked:
             self._check_registry(make_desc(b, self.in_channel, self.n_classes, x.shape[2], x.shape[3], x.shape[4],
                                            self.width_mult, meta["dtype"], self.conv_impl, self.negative_slope))
@@ -323,6 +337,7 @@ class CapturedForward:
             self.drop1 = torch.ones((batch, 24), dtype=torch.float32, device=dev)
             self.drop2 = torch.ones((batch, 12), dtype=torch.float32, device=dev)
             self._stream = torch.cuda.Stream(device=dev)
+            self._last = torch.cuda.Event()
         self._graphs = {}           # training flag -> (handle, parameter pointers, kept-alive tensors)
 
     def _record(self, training: bool):
@@ -344,7 +359,7 @@ class CapturedForward:
         cur.wait_stream(self._stream)
         old = self._graphs.get(training)
         if old is not None:
-            lib.seunet_graph_destroy(old[0])
+            self._destroy(old[0])
         self._graphs[training] = (handle, [p.data_ptr() for p in plist], plist)
 
     def __call__(self):
@@ -361,13 +376,18 @@ class CapturedForward:
                 self._record(training)
                 g = self._graphs[training]
             _lib.check(lib.seunet_graph_launch(g[0], _lib.stream_ptr()), "graph_launch")
+            self._last.record(torch.cuda.current_stream(self.device))   # (a graph is destroyed only after its last replay has run)
         return self.pred0, self.pred1
+
+    def _destroy(self, handle):
+        # the host runs several replays ahead of the GPU: wait for the last launched replay before the executable graph goes
+        self._last.synchronize()
+        _lib.load().seunet_graph_destroy(handle)
 
     def __del__(self):
         try:
-            lib = _lib.load()
             for g in self._graphs.values():
-                lib.seunet_graph_destroy(g[0])
+                self._destroy(g[0])
         except Exception:
             pass
 

@@ -51,14 +51,17 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
     x = x.contiguous().float()
     _, C_, X, Y, Z = x.shape
     max_call = 64                                       # windows per native call (kernel-argument table)
-    # one case over several GPUs (one process per GPU, every rank holds the volume): the BATCHES of the window list are
-    # dealt round-robin, each rank accumulates its windows, and the float64 accumulators are summed by one all-reduce
-    # before the division by the overlap count -- the only exchange step of the loop
+    # one case over several GPUs (one process per GPU, every rank holds the volume): the WINDOWS of the list are dealt
+    # round-robin by their index (rank r takes windows r, r + world, ...: a partition that does not depend on any rank's
+    # batch size, which auto_batch() derives from that rank's free memory), each rank batches and accumulates its own
+    # windows, and the float64 accumulators are summed by one all-reduce before the division by the overlap count -- the
+    # only exchange step of the loop
     world, rank, pg = 1, 0, None
     if group is not None and group is not False:
         import torch.distributed as dist
         pg = None if group is True else group
         world, rank = dist.get_world_size(pg), dist.get_rank(pg)
+        pos = pos[rank::world]
     with torch.cuda.device(x.device):
         st = _lib.stream_ptr()
         acc = torch.zeros((X, Y, Z), dtype=torch.float64, device=x.device)
@@ -68,9 +71,7 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
         if graph and len(pos) >= 2 * batch:
             from .SE_UNet import CapturedForward
             cap = CapturedForward(model, batch, (cube, cube, cube))
-        for bi, i in enumerate(range(0, len(pos), batch)):
-            if bi % world != rank:
-                continue
+        for i in range(0, len(pos), batch):
             chunk = pos[i:i + batch]
             use_cap = cap is not None and len(chunk) == batch
             xin = cap.x if use_cap else torch.empty((len(chunk), C_, cube, cube, cube), dtype=torch.float32, device=x.device)
@@ -97,7 +98,8 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
 
 def auto_batch(model, device, cube: int = 128, cap: int = 16) -> int:
     """Windows per network call for the prediction-form loop when the caller does not say: the reference runs one window
-    per call (prediction.py:103); in eval mode any batch gives the same volume (InstanceNorm is per sample), and larger
+    per call (prediction.py:103); in eval mode any batch gives the same volume up to f32 rounding of the InstanceNorm
+    statistics (InstanceNorm is per sample; the number of partial sums per sample follows the batch size), and larger
     batches amortise the small coarse-level kernels (512^3 on MI355X: 0.65 s at 1, 0.49 s at 4, 0.455 s at 16).  The largest
     power of two <= ``cap`` whose workspace (3.3 GB per 128^3 window in 16-bit storage) fits the free HBM with room to spare;
     1 under ``model.train()`` (DropLayer's scale depends on the batch size, SE_UNet.py:91-96)."""
@@ -124,13 +126,14 @@ def sliding_window_predict(model, x: torch.Tensor, cube: int = 128, step: int = 
     """prediction.py:78-109.  x: (1, C, X, Y, Z) on the GPU.  Returns the overlap-averaged sigmoid(pred1) volume as
     float64 numpy (like the reference's host accumulators), or the float64 CUDA tensor with ``return_tensor=True`` (what
     ``double_threshold_iteration`` takes next, prediction.py:110).  ``batch`` windows go through the network per call
-    (the reference uses 1; results are identical in eval mode because InstanceNorm is per sample; ``None`` = ``auto_batch``).  ``graph``: replay the
-    forward pass as one recorded HIP graph per batch (``CapturedForward``: same kernels, same bits).  Off by default: on
+    (the reference uses 1; in eval mode the result does not depend on it beyond f32 rounding of the statistics, because
+    InstanceNorm is per sample; ``None`` = ``auto_batch``).  ``graph``: replay the forward pass as one recorded HIP graph per
+    batch (``CapturedForward``: same kernels, same bits as the eager call at the same batch size).  Off by default: on
     MI355X the loop is bound by the kernels, not by their launches (512^3: 0.499 s replayed vs 0.493 s launched one by
     one at batch 4, 0.656 vs 0.648 s at batch 1); it pays only when the host thread is slow or busy.
     ``group`` (``True`` = the default process group, or a ``ProcessGroup``): shard the windows of this ONE case over the
-    ranks (every rank passes the same volume and gets the full result; the window batches are dealt round-robin and the
-    float64 accumulators all-reduced once, RCCL on GPUs).  Eval mode only gives rank-count-independent results
+    ranks (every rank passes the same volume and gets the full result; the windows are dealt round-robin by index -- ranks
+    may use different batch sizes -- and the float64 accumulators all-reduced once, RCCL on GPUs).  Eval mode only gives rank-count-independent results
     (DropLayer draws are per call)."""
     pos = window_table(x.shape[2:], cube, step)
     if batch is None:
