@@ -65,6 +65,7 @@ class SSEConv(nn.Module):
         self.conv1 = nn.Conv3d(in_channel, out_channel1, 3, padding=dilation, dilation=dilation, bias=True)
         self.conv2 = nn.Conv3d(out_channel1, 2, 1, bias=True)
         self.conv_se = nn.Conv3d(out_channel1, 1, 1, bias=False)
+        self.act = nn.LeakyReLU(inplace=True)     # (reference attribute SE_UNet.py:18; its slope is what the fused epilogue uses)
         if self.n_gates == 2:
             self.conv_se2 = nn.Conv3d(out_channel1, 1, 1, bias=False)
 
@@ -85,6 +86,7 @@ class CATConv(nn.Module):
         super().__init__()
         self.in_channel, self.out_channel = in_channel, out_channel1
         self.conv1 = nn.Conv3d(in_channel, out_channel1, 1, bias=False)
+        self.act = nn.LeakyReLU(inplace=True)     # (SE_UNet.py:44)
 
     def forward(self, x):
         from .ops import cat_block_forward
@@ -256,6 +258,9 @@ class SE_UNet(nn.Module):
         self.dc0_1 = nn.Conv3d(12, n_classes, 1, bias=True)
         self.dropout1 = DropLayer(channel_num=24, thr=0.3)
         self.dropout2 = DropLayer(channel_num=12, thr=0.3)
+        for m in self.modules():                 # the blocks' own activation modules carry this network's slope
+            if isinstance(getattr(m, "act", None), nn.LeakyReLU):
+                m.act.negative_slope = float(negative_slope)
         self._names = [n for n, _ in self.named_parameters()]
         self._dead = [n.startswith("dc62.") for n in self._names]
         self._registry_checked = False

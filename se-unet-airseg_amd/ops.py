@@ -500,10 +500,10 @@ def gated_block_forward(mod, x: torch.Tensor):
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
     w_se2 = mod.conv_se2.weight if getattr(mod, "conv_se2", None) is not None else None
     return _GatedBlockFn.apply(x.contiguous().float(), mod.conv1.weight, mod.conv1.bias, mod.conv_se.weight, w_se2,
-                               mod.conv2.weight, mod.conv2.bias, mod.dilation, mod.down_sample, float(mod.relu.negative_slope))
+                               mod.conv2.weight, mod.conv2.bias, mod.dilation, mod.down_sample, float(mod.act.negative_slope))
 
 
 def cat_block_forward(mod, x: torch.Tensor):
     if not x.is_cuda:
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
-    return _CatBlockFn.apply(x.contiguous().float(), mod.conv1.weight, float(mod.relu.negative_slope))
+    return _CatBlockFn.apply(x.contiguous().float(), mod.conv1.weight, float(mod.act.negative_slope))
