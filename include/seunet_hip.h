@@ -316,6 +316,11 @@ int seunet_net_forward_capture(const seunet_net_desc* desc, const float* const* 
                                seunet_stream_t s, void** graph_out);
 int seunet_graph_launch(void* graph, seunet_stream_t s);
 int seunet_graph_destroy(void* graph);
+/* diagnostic: read one intermediate of the last forward that ran on `workspace` back as f32 (which = 0 raw conv output of block
+ * `name` [NCDHW], 1 / 2 its InstanceNorm mean / rstd [N][C], 3 the block's output tensor [NCDHW]); *channels = its channel count.
+ * Nothing is recomputed; the product path does not call it (scripts/flip_census.py does). */
+int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, size_t workspace_bytes, const char* name, int which,
+                           float* out, int* channels, seunet_stream_t s);
 /* grads: device pointers in registry order, each overwritten (NULL = skip).  The dead block dc62
  * (SE_UNet.py:148,230) receives no gradient: its entry is never written. */
 int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,

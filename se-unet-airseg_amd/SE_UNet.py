@@ -274,6 +274,47 @@ class SE_UNet(nn.Module):
             raise RuntimeError("parameter registry of libseunet_hip differs from the nn.Module's state_dict")
         self._registry_checked = True
 
+    @torch.no_grad()
+    def forward_with_intermediates(self, x, blocks):
+        """Diagnostic (eval-mode forward, no autograd): ``(pred0, pred1, {block: {"raw", "mean", "rstd", "out"}})`` for the
+        named blocks -- the raw conv output, its InstanceNorm statistics and the block's output tensor as the kernels left
+        them in the workspace (``seunet_net_read_tensor``).  scripts/flip_census.py counts LeakyReLU-sign and max-pool-argmax
+        disagreements with the float64 oracle from these."""
+        lib = _lib.load()
+        x = x.contiguous().float()
+        b, _, d, h, w = x.shape
+        desc = make_desc(b, self.in_channel, self.n_classes, d, h, w, self.width_mult, _lib.dtype_code(self.act_dtype),
+                         self.conv_impl, self.negative_slope)
+        level = {"ec1": 0, "ec2": 0, "ec3": 0, "ec33": 0, "dc5": 0, "dc6": 0, "ec4": 1, "ec5": 1, "ec6": 1, "ec63": 1, "dc3": 1,
+                 "dc4": 1, "dc42": 1, "ec7": 2, "ec8": 2, "ec9": 2, "ec93": 2, "dc1": 2, "dc2": 2, "dc22": 2, "ec10": 3, "ec11": 3,
+                 "ec12": 3, "ec123": 3}
+        with torch.cuda.device(x.device):
+            nbytes = lib.seunet_net_workspace_bytes(C.byref(desc))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            pred0 = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
+            pred1 = torch.empty_like(pred0)
+            plist = [p.detach().contiguous() for p in self.parameters()]
+            _lib.check(lib.seunet_net_forward(C.byref(desc), _lib.ptr_array(plist), x.data_ptr(), None, None, pred0.data_ptr(),
+                                              pred1.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr()), "net_forward")
+
+            def read(name, which, buf, ch=None):
+                _lib.check(lib.seunet_net_read_tensor(C.byref(desc), ws.data_ptr(), nbytes, name.encode(), which, buf.data_ptr(),
+                                                      ch, _lib.stream_ptr()), "net_read_tensor")
+            out = {}
+            for name in blocks:
+                ch = C.c_int(0)
+                tmp = torch.empty((b, 512), dtype=torch.float32, device=x.device)
+                read(name, 1, tmp, C.byref(ch))
+                c = ch.value
+                rec = {"mean": tmp.reshape(-1)[:b * c].reshape(b, c).clone(), "rstd": torch.empty((b, c), dtype=torch.float32, device=x.device)}
+                read(name, 2, rec["rstd"])
+                lv = level[name]
+                for key, which in (("raw", 0), ("out", 3)):
+                    rec[key] = torch.empty((b, c, d >> lv, h >> lv, w >> lv), dtype=torch.float32, device=x.device)
+                    read(name, which, rec[key])
+                out[name] = rec
+        return pred0, pred1, out
+
     def forward(self, x, drop_scales: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         """x: (B, in_channel, D, H, W) float, D/H/W multiples of 8 -> (pred0, pred1) logits.
         ``drop_scales`` optionally injects the two DropLayer scale tensors (B,24,1,1,1)/(B,12,1,1,1)."""

@@ -24,7 +24,7 @@
 //     step that re-initialises it (the first MFMA of a row takes the bias vector / zero as its C operand, so nothing is
 //     ever zeroed), i.e. the epilogue of plane j runs under the MFMAs of plane j+3; gradient accumulation (+=) reads the
 //     old destination rows through a second LDS-DMA ring one step ahead;
-//   * InstanceNorm partial sums per lane in f32 per plane, carried in f64 across the march, one record per workgroup.
+//   * InstanceNorm partial sums per lane in f32 (per plane, then across the march), f64 across lanes, one record per workgroup.
 // One workgroup per CU: a 4 x 128^3 batch at 64 -> 32 channels is exactly 256 marches of 128 planes.
 #include "seunet_common.h"
 #include <utility>
@@ -258,10 +258,12 @@ conv_march_kernel(MarchArgs a) {
   for (int e = 0; e < 4; ++e) cinit[e] = (MODE == 0 && a.bias != nullptr) ? a.bias[co0 + 4 * g + e] : 0.f;
 
   // InstanceNorm sums of this lane's 4 channels: f32 inside a plane, f64 across the march
+  // (two-level f32: 16 values per plane, one add per plane into the march total -- 8 fewer registers than f64 totals, which
+  // the 216-weight-register forward variant does not have; the cross-lane / cross-workgroup sums are f64)
   float s1[4], s2[4];
-  double S1[4], S2[4];
+  float S1[4], S2[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; S1[e] = 0.0; S2[e] = 0.0; }
+  for (int e = 0; e < 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; S1[e] = 0.f; S2[e] = 0.f; }
 
   const int yrow0 = y0 + rg * RYW;
   const bool okx0 = x0 + n16 < a.W, okx1 = x0 + 16 + n16 < a.W;
@@ -307,7 +309,7 @@ conv_march_kernel(MarchArgs a) {
   auto flush_stats = [&]() __attribute__((always_inline)) {
     if constexpr (MODE == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { S1[e] += (double)s1[e]; S2[e] += (double)s2[e]; s1[e] = 0.f; s2[e] = 0.f; }
+      for (int e = 0; e < 4; ++e) { S1[e] += s1[e]; S2[e] += s2[e]; s1[e] = 0.f; s2[e] = 0.f; }
     }
   };
 
@@ -401,10 +403,13 @@ conv_march_kernel(MarchArgs a) {
   });
   march_wait_vm<(MA_PF - 1) * ITEMS>();    // plane 0 has landed (this wave's part)
   __builtin_amdgcn_s_barrier();
-  // Every step is a compute step: the steps beyond the last input plane march over zero planes (DMA from the zero page) and
-  // exist for their lazy epilogues; the trip count is padded to whole 3-step rounds so that the loop body has no conditional
-  // path (the accumulator sets stay in place: no copies, no merges).
-  const int nrounds = (ncompute + 1 + 2) / 3;
+  // Every step of the loop is a compute step and the trip count is padded to whole 3-step rounds, so that the loop body has no
+  // conditional path (the accumulator sets stay in place: no copies, no merges); steps beyond the last input plane march over
+  // zero planes (DMA from the zero page).  The rows 1.. of the LAST output plane Z - 1 (set (Z - 1) % 3) are written by the
+  // lazy epilogue of step Z + 2 when the padding reaches that step; when Z + 2 is a multiple of 3 the loop ends before it and a
+  // tail without MFMAs writes them (then (Z - 1) % 3 == 0: one variant of the tail).  launch_conv_march() prefers such
+  // segment lengths.
+  const int nrounds = (ncompute + 2) / 3;
   int slot = 0, slot_pf = MA_PF % MA_RING;
   for (int rd3 = 0; rd3 < nrounds; ++rd3) {
     static_for<3>([&](auto ph_c) __attribute__((always_inline)) {
@@ -420,6 +425,15 @@ conv_march_kernel(MarchArgs a) {
     });
   }
   march_wait_vm<0>();            // no DMA may outlive the workgroup's LDS allocation
+  if (3 * nrounds == ncompute) {   // (wave-uniform) the tail: rows 1.. of output Z - 1, held in set 0, as step Z + 2 would have
+    // (accumulation: a wave reads only the old rows it fetched itself, and they have landed: vmcnt(0) above)
+    static_for<RYW - 1>([&](auto r_c) __attribute__((always_inline)) {
+      constexpr int r = decltype(r_c)::value + 1;
+      finish_blk(ncompute, ncompute - 3, std::integral_constant<int, 0>{}, std::integral_constant<int, r>{}, std::integral_constant<int, 0>{});
+      finish_blk(ncompute, ncompute - 3, std::integral_constant<int, 0>{}, std::integral_constant<int, r>{}, std::integral_constant<int, 1>{});
+    });
+    flush_stats();
+  }
 
   // ---- InstanceNorm partial sums of this workgroup: over the 16 lanes that hold the same channels, then over the row
   //      groups (fixed order), one record per workgroup ----
@@ -429,7 +443,7 @@ conv_march_kernel(MarchArgs a) {
       double* red = reinterpret_cast<double*>(smem);     // [4 waves][16 channels][2]
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        double t1 = S1[e], t2 = S2[e];
+        double t1 = (double)S1[e], t2 = (double)S2[e];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) { t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
         if (n16 == 0) {
@@ -477,6 +491,28 @@ conv_march_pack_kernel(MarchPackArgs p) {
   }
 }
 
+// all the weight tensors of a pass in one launch: blockIdx.y = list entry
+struct MarchPackList { MarchPackArgs e[12]; int blocks[12]; };
+template <typename T>
+__global__ void __launch_bounds__(64)
+conv_march_pack_multi_kernel(MarchPackList l) {
+  const MarchPackArgs& p = l.e[blockIdx.y];
+  if ((int)blockIdx.x >= l.blocks[blockIdx.y]) return;
+  const int lane = threadIdx.x;
+  const int ks = blockIdx.x % p.ks, gt = blockIdx.x / p.ks;
+  const int tap = gt % 27, grp = gt / 27;
+  const int co = grp * 16 + (lane & 15);
+  const int kg = lane >> 4;
+  T* out = reinterpret_cast<T*>(p.out) + ((size_t)blockIdx.x * 64 + lane) * 8;
+  for (int j = 0; j < 8; ++j) {
+    const int ci = 32 * ks + 8 * kg + j;
+    float v = 0.f;
+    if (co < p.cout_e && ci < p.cin_e)
+      v = p.tflip ? p.w[((long long)ci * p.cin_w + co) * 27 + (26 - tap)] : p.w[((long long)co * p.cin_w + ci) * 27 + tap];
+    out[j] = from_f32<T>(v);
+  }
+}
+
 // ---- configuration by channel counts -------------------------------------------------------------------------------
 // mode as in the kernel: 0 forward, 1 data gradient, 2 data gradient with accumulation
 struct MarchCfg { int ks, ngw, ryw; };
@@ -500,16 +536,15 @@ bool conv_march_supported(int dtype, int taps, int dil, const SrcList& src, cons
 size_t conv_march_wpack_bytes(int cin_e, int cout_e) { return (size_t)(cout_e / 16) * 27 * (cin_e / 32) * 64 * 16; }
 
 static int march_patch_rows(const MarchCfg& c) { return c.ryw * (MA_NW / c.ngw); }
-// output planes per march: the fewest rounds of workgroups over the chip's 256 CUs (one workgroup per CU), then the longest
-// marches (every march runs 3 steps beyond its planes)
+// output planes per march: the fewest steps on the critical path -- rounds of workgroups over the chip's 256 CUs (one
+// workgroup per CU) x steps of the longest march, a march of Z planes running Z + 2 steps rounded up to a multiple of 3
 static int march_zsteps(int planes, long long wg_per_seg) {
   int best = planes;
   long long best_cost = -1;
-  for (int segs = 1; segs <= 8 && segs <= planes; ++segs) {
-    const int zs = (planes + segs - 1) / segs;
-    const int real_segs = (planes + zs - 1) / zs;
-    const long long rounds = (wg_per_seg * real_segs + 255) / 256;
-    const long long cost = rounds * (zs + 3);
+  for (int zs = planes; zs >= 1 && zs * 8 >= planes; --zs) {
+    const int segs = (planes + zs - 1) / zs;
+    const long long rounds = (wg_per_seg * segs + 255) / 256;
+    const long long cost = rounds * ((zs + 2 + 2) / 3 * 3);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = zs; }
   }
   return best;
@@ -534,6 +569,28 @@ int launch_conv_march_pack(int dtype, const float* w, int cin_w, int cout_w, int
   const int blocks = (cout_e / 16) * 27 * c.ks;
   if (dtype == SEUNET_F16) conv_march_pack_kernel<f16_t><<<blocks, 64, 0, s>>>(p);
   else conv_march_pack_kernel<bf16_t><<<blocks, 64, 0, s>>>(p);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv_march_pack_multi(int dtype, const MarchPackJob* jobs, int n, hipStream_t s) {
+  for (int base = 0; base < n; base += 12) {
+    MarchPackList l{};
+    const int m = n - base < 12 ? n - base : 12;
+    int maxb = 0;
+    for (int i = 0; i < m; ++i) {
+      const MarchPackJob& j = jobs[base + i];
+      MarchCfg c;
+      SEUNET_CHECK(march_cfg(dtype, 27, 1, j.cin_e, j.cout_e, 0, c) && j.w && j.wpack, "conv_march_pack: unsupported shape (%d -> %d channels)", j.cin_e, j.cout_e);
+      const int we_in = j.tflip ? j.cout_w : j.cin_w, we_out = j.tflip ? j.cin_w : j.cout_w;
+      SEUNET_CHECK(we_in <= j.cin_e && we_out <= j.cout_e, "conv_march_pack: weight (%d -> %d) exceeds the tensors (%d -> %d)", we_in, we_out, j.cin_e, j.cout_e);
+      l.e[i] = MarchPackArgs{j.w, j.wpack, j.cin_w, j.cout_w, j.tflip, we_in, we_out, c.ks};
+      l.blocks[i] = (j.cout_e / 16) * 27 * c.ks;
+      maxb = l.blocks[i] > maxb ? l.blocks[i] : maxb;
+    }
+    if (dtype == SEUNET_F16) conv_march_pack_multi_kernel<f16_t><<<dim3(maxb, m), 64, 0, s>>>(l);
+    else conv_march_pack_multi_kernel<bf16_t><<<dim3(maxb, m), 64, 0, s>>>(l);
+  }
   SEUNET_LAUNCH_CHECK();
   return 0;
 }

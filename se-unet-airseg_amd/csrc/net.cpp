@@ -362,6 +362,7 @@ struct Exec {
     if (p.d.conv_impl == SEUNET_CONV_NAIVE) return 0;
     mark("pack_w");
     std::vector<ConvPackJob> jobs;
+    std::vector<MarchPackJob> mjobs;
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
       if (o.kind != OP_GATED && o.kind != OP_CAT) continue;
@@ -377,8 +378,8 @@ struct Exec {
       if ((!dgrad && r.march_f) || (dgrad && r.march_d)) {
         int ctot = 0;
         for (int k = 0; k < o.nsrc; ++k) ctot += p.C[o.src[k]];
-        if (int e = launch_conv_march_pack(p.d.dtype, P(n + ".conv1.weight"), r.cin, r.cout, dgrad ? 1 : 0, dgrad ? r.cout : ctot,
-                                           dgrad ? ctot : r.cout, at(dgrad ? r.wp_d : r.wp_f), s)) return e;
+        mjobs.push_back({P(n + ".conv1.weight"), at(dgrad ? r.wp_d : r.wp_f), r.cin, r.cout, dgrad ? 1 : 0, dgrad ? r.cout : ctot,
+                         dgrad ? ctot : r.cout});
         continue;
       }
       if (!dgrad) {
@@ -388,6 +389,8 @@ struct Exec {
         jobs.push_back({P(n + ".conv1.weight"), at(r.wp_d), r.taps, r.cin, r.cout, 1});
       }
     }
+    if (!mjobs.empty())
+      if (int e = launch_conv_march_pack_multi(p.d.dtype, mjobs.data(), (int)mjobs.size(), s)) return e;
     return launch_conv_pack_weights_multi(p.d.dtype, jobs.data(), (int)jobs.size(), s);
   }
 
@@ -715,6 +718,32 @@ int seunet_graph_destroy(void* graph) {
   if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
   return 0;
+}
+
+// Diagnostic read-back of one intermediate of the LAST forward that ran on `workspace` (nothing is recomputed): which = 0 the
+// raw conv output of block `name` (before InstanceNorm; NCDHW f32, `channels` of them), 1 / 2 its per-(n, c) mean / rstd
+// ([N][C] f32), 3 the block's output tensor (for an aggregation block: after the x-branch was added; NCDHW f32).  Used by the
+// flip census (scripts/flip_census.py): LeakyReLU sign / max-pool argmax disagreements with the float64 oracle.
+int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, size_t workspace_bytes, const char* name, int which,
+                           float* out, int* channels, seunet_stream_t s) {
+  SEUNET_CHECK(desc && workspace && name && out, "net_read_tensor: null argument");
+  Plan p;
+  if (int e = p.init(*desc)) return e;
+  SEUNET_CHECK(workspace_bytes >= p.total, "net_read_tensor: workspace too small");
+  const unsigned char* ws = reinterpret_cast<const unsigned char*>(workspace);
+  for (int i = 0; i < kNumOps; ++i) {
+    const OpDesc& o = kOps[i];
+    if ((o.kind != OP_GATED && o.kind != OP_CAT) || std::string(o.name) != name) continue;
+    const OpRes& r = p.op[i];
+    const int lv = kT[o.dst].level;
+    if (channels) *channels = which == 3 ? p.C[o.dst] : r.cout;
+    if (which == 0) return launch_unpack_cl(p.d.dtype, ws + r.raw, r.cout, out, p.dims[lv], (hipStream_t)s);
+    if (which == 3) return launch_unpack_cl(p.d.dtype, ws + p.feat[o.dst], p.C[o.dst], out, p.dims[lv], (hipStream_t)s);
+    SEUNET_CHECK(which == 1 || which == 2, "net_read_tensor: which=%d", which);
+    SEUNET_HIP(hipMemcpyAsync(out, ws + (which == 1 ? r.mean : r.rstd), (size_t)p.d.batch * r.cout * 4, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return 0;
+  }
+  return fail("net_read_tensor: no block named %s", name);
 }
 
 int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,

@@ -239,6 +239,8 @@ bool conv_march_supported(int dtype, int taps, int dil, const SrcList& src, cons
 size_t conv_march_wpack_bytes(int cin_e, int cout_e);
 int conv_march_slots(Dims d, int dil, int cin_e, int cout_e);
 int launch_conv_march_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int cin_e, int cout_e, void* wpack, hipStream_t s);
+struct MarchPackJob { const float* w; void* wpack; int cin_w, cout_w, tflip, cin_e, cout_e; };
+int launch_conv_march_pack_multi(int dtype, const MarchPackJob* jobs, int n, hipStream_t s);   // every layer of a pass in one launch
 int launch_conv_march(int dtype, int dil, const SrcList& src, const void* wpack, const float* bias, const DstList& dst, double* stats,
                       Dims d, hipStream_t s);
 
