@@ -318,7 +318,7 @@ int seunet_graph_launch(void* graph, seunet_stream_t s);
 int seunet_graph_destroy(void* graph);
 /* diagnostic: read one intermediate of the last forward that ran on `workspace` back as f32 (which = 0 raw conv output of block
  * `name` [NCDHW], 1 / 2 its InstanceNorm mean / rstd [N][C], 3 the block's output tensor [NCDHW]); *channels = its channel count.
- * Nothing is recomputed; the product path does not call it (scripts/flip_census.py does). */
+ * Nothing is recomputed; the product path does not call it (tests/flip_census.py does). */
 int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, size_t workspace_bytes, const char* name, int which,
                            float* out, int* channels, seunet_stream_t s);
 /* grads: device pointers in registry order, each overwritten (NULL = skip).  The dead block dc62

@@ -278,7 +278,7 @@ class SE_UNet(nn.Module):
     def forward_with_intermediates(self, x, blocks):
         """Diagnostic (eval-mode forward, no autograd): ``(pred0, pred1, {block: {"raw", "mean", "rstd", "out"}})`` for the
         named blocks -- the raw conv output, its InstanceNorm statistics and the block's output tensor as the kernels left
-        them in the workspace (``seunet_net_read_tensor``).  scripts/flip_census.py counts LeakyReLU-sign and max-pool-argmax
+        them in the workspace (``seunet_net_read_tensor``).  tests/flip_census.py counts LeakyReLU-sign and max-pool-argmax
         disagreements with the float64 oracle from these."""
         lib = _lib.load()
         x = x.contiguous().float()
@@ -287,7 +287,7 @@ class SE_UNet(nn.Module):
                          self.conv_impl, self.negative_slope)
         level = {"ec1": 0, "ec2": 0, "ec3": 0, "ec33": 0, "dc5": 0, "dc6": 0, "ec4": 1, "ec5": 1, "ec6": 1, "ec63": 1, "dc3": 1,
                  "dc4": 1, "dc42": 1, "ec7": 2, "ec8": 2, "ec9": 2, "ec93": 2, "dc1": 2, "dc2": 2, "dc22": 2, "ec10": 3, "ec11": 3,
-                 "ec12": 3, "ec123": 3}
+                 "ec12": 3, "ec123": 3, "x33": 0, "x63": 1, "x93": 2}   # (x-branches: only when materialised, in_channel > 2)
         with torch.cuda.device(x.device):
             nbytes = lib.seunet_net_workspace_bytes(C.byref(desc))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -310,6 +310,8 @@ class SE_UNet(nn.Module):
                 read(name, 2, rec["rstd"])
                 lv = level[name]
                 for key, which in (("raw", 0), ("out", 3)):
+                    if which == 3 and name.startswith("x"):
+                        continue
                     rec[key] = torch.empty((b, c, d >> lv, h >> lv, w >> lv), dtype=torch.float32, device=x.device)
                     read(name, which, rec[key])
                 out[name] = rec

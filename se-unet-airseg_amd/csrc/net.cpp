@@ -723,7 +723,7 @@ int seunet_graph_destroy(void* graph) {
 // Diagnostic read-back of one intermediate of the LAST forward that ran on `workspace` (nothing is recomputed): which = 0 the
 // raw conv output of block `name` (before InstanceNorm; NCDHW f32, `channels` of them), 1 / 2 its per-(n, c) mean / rstd
 // ([N][C] f32), 3 the block's output tensor (for an aggregation block: after the x-branch was added; NCDHW f32).  Used by the
-// flip census (scripts/flip_census.py): LeakyReLU sign / max-pool argmax disagreements with the float64 oracle.
+// flip census (tests/flip_census.py): LeakyReLU sign / max-pool argmax disagreements with the float64 oracle.
 int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, size_t workspace_bytes, const char* name, int which,
                            float* out, int* channels, seunet_stream_t s) {
   SEUNET_CHECK(desc && workspace && name && out, "net_read_tensor: null argument");
@@ -733,9 +733,18 @@ int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, s
   const unsigned char* ws = reinterpret_cast<const unsigned char*>(workspace);
   for (int i = 0; i < kNumOps; ++i) {
     const OpDesc& o = kOps[i];
-    if ((o.kind != OP_GATED && o.kind != OP_CAT) || std::string(o.name) != name) continue;
+    if (o.kind != OP_GATED && o.kind != OP_CAT) continue;
     const OpRes& r = p.op[i];
     const int lv = kT[o.dst].level;
+    if (o.xname && std::string(o.xname) == name) {   // the raw-input branch of an aggregation block, when it is materialised (in_channel > 2)
+      SEUNET_CHECK(!p.fuse_x, "net_read_tensor: %s is recomputed inside the aggregation epilogue in this configuration (in_channel <= 2), it has no tensor", name);
+      SEUNET_CHECK(which >= 0 && which <= 2, "net_read_tensor: which=%d is not stored for an x-branch", which);
+      if (channels) *channels = r.cout;
+      if (which == 0) return launch_unpack_cl(p.d.dtype, ws + r.raw2, r.cout, out, p.dims[lv], (hipStream_t)s);
+      SEUNET_HIP(hipMemcpyAsync(out, ws + (which == 1 ? r.mean2 : r.rstd2), (size_t)p.d.batch * r.cout * 4, hipMemcpyDeviceToDevice, (hipStream_t)s));
+      return 0;
+    }
+    if (std::string(o.name) != name) continue;
     if (channels) *channels = which == 3 ? p.C[o.dst] : r.cout;
     if (which == 0) return launch_unpack_cl(p.d.dtype, ws + r.raw, r.cout, out, p.dims[lv], (hipStream_t)s);
     if (which == 3) return launch_unpack_cl(p.d.dtype, ws + p.feat[o.dst], p.C[o.dst], out, p.dims[lv], (hipStream_t)s);
