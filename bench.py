@@ -169,6 +169,9 @@ def main():
     # RCCL ("nccl") is the backend for real runs; SEUNET_DIST_BACKEND=gloo lets two ranks share one GPU for rehearsal
     backend = os.environ.get("SEUNET_DIST_BACKEND", "nccl")
     local = ddp.init_from_env(backend)
+    if dist.is_initialized() and dist.get_backend() != "nccl" and "SEUNET_DIST_BACKEND" not in os.environ:
+        raise SystemExit(f"bench.py: the multi-GPU exchange must run over RCCL (torch backend 'nccl'), got {dist.get_backend()!r}; "
+                         "set SEUNET_DIST_BACKEND=gloo only to rehearse the launcher on one GPU")
     local = local % max(torch.cuda.device_count(), 1)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -192,7 +195,14 @@ def main():
     label = (torch.rand((B, 1, S, S, S), generator=g, device=dev) < 0.03).float()
     group = True if world > 1 else None
 
+    # data parallel: the exchange is overlapped with the backward pass (decoder bucket on a side stream behind an event the
+    # library records, the rest after the backward; ddp.GradSync).  SEUNET_DDP_SERIAL=1: one all-reduce after the backward.
+    overlap = world > 1 and not os.environ.get("SEUNET_DDP_SERIAL")
+
     def make_step(model, opt, ar_events=None):
+        if overlap:
+            model.grad_sync = ddp.GradSync(timing=ar_events is not None)
+
         def step():
             if opt is not None:
                 opt.zero_grad(set_to_none=True)
@@ -202,7 +212,7 @@ def main():
             pe, pd = model(x)
             loss = A.fused_stage_loss(1, pe, pd, label, group=group)
             loss.backward()
-            if world > 1:
+            if world > 1 and not overlap:
                 if ar_events is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -293,6 +303,8 @@ def main():
     # ---- the timed region: EXACTLY --steps steps, only the dominant launch group bracketed by events (two events per
     # step; a fully marked step is ~5 % slower)
     ar_events.clear()
+    if overlap:
+        model.grad_sync.elapsed_ms()       # (drop the warm-up's marks)
     if dom_tag and not args.no_kernel_timing:
         lib.seunet_prof_enable_filtered(dom_tag.encode())
     dt, per_step_ms, loss = timed(step, args.steps)
@@ -304,7 +316,7 @@ def main():
     voxels_step = world * B * S ** 3
     value = voxels_step * args.steps / dt
     ms_step = 1e3 * dt / args.steps
-    ar_ms = [a.elapsed_time(b) for a, b in ar_events]
+    ar_ms = model.grad_sync.elapsed_ms() if overlap else [a.elapsed_time(b) for a, b in ar_events]
     if rank == 0:
         print("per-step ms: " + " ".join(f"{v:.2f}" for v in per_step_ms), file=sys.stderr)
 
@@ -314,14 +326,16 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"SE-UNet base x{args.width} ({args.in_channel}-ch input), {B}x{S}^3 patches per GPU, "
                                f"fwd + stage-1 Dice loss + bwd" + ("" if args.no_optimizer else " + AdamW step")
-                               + (" + flat-bucket RCCL all-reduce" if world > 1 else ""),
+                               + ((" + gradient all-reduce over %s (%s)" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+                                                                              "decoder bucket overlapped with the encoder's backward" if overlap
+                                                                              else "one flat bucket after the backward")) if world > 1 else ""),
                    "global_batch": B * world, "patch": S, "parallelism": f"dp{world}", "world_size": world,
                    "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                    "droplayer": "train" if args.train_mode else "eval", "final_loss": float(loss.detach())},
         "median_ms_per_step": statistics.median(per_step_ms), "max_ms_per_step": max(per_step_ms),
     }
     if ar_ms:
-        out["config"]["grad_allreduce_ms"] = {"median": statistics.median(ar_ms), "max": max(ar_ms),
+        out["config"]["grad_allreduce_ms"] = {"median": statistics.median(ar_ms), "max": max(ar_ms), "exposed_only": bool(overlap),
                                               "elements": sum(p.numel() for n, p in model.named_parameters() if not n.startswith("dc62."))}
     if args.in_channel == 2 and args.width in MODEL_FLOP_PER_VOXEL:
         per_gpu_vox = B * S ** 3

@@ -318,14 +318,22 @@ int seunet_graph_launch(void* graph, seunet_stream_t s);
 int seunet_graph_destroy(void* graph);
 /* diagnostic: read one intermediate of the last forward that ran on `workspace` back as f32 (which = 0 raw conv output of block
  * `name` [NCDHW], 1 / 2 its InstanceNorm mean / rstd [N][C], 3 the block's output tensor [NCDHW]); *channels = its channel count.
- * Nothing is recomputed; the product path does not call it (tests/flip_census.py does). */
-int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, size_t workspace_bytes, const char* name, int which,
-                           float* out, int* channels, seunet_stream_t s);
+ * `name` may be an x-branch (x33 / x63 / x93; which 0..2): with in_channel <= 2 its raw values exist nowhere and are recomputed
+ * from the packed input by the device function the aggregation epilogue uses (params = the forward's parameter list; may be
+ * NULL otherwise).  The product path does not call this (tests/flip_census.py and the same-choice gradient gate do). */
+int seunet_net_read_tensor(const seunet_net_desc* desc, const float* const* params, const void* workspace, size_t workspace_bytes,
+                           const char* name, int which, float* out, int* channels, seunet_stream_t s);
 /* grads: device pointers in registry order, each overwritten (NULL = skip).  The dead block dc62
  * (SE_UNet.py:148,230) receives no gradient: its entry is never written. */
 int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
                         const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
                         void* workspace, size_t workspace_bytes, seunet_stream_t s);
+/* the same, recording `decoder_done_event` (a hipEvent_t, or NULL) on the stream once the parameter gradients of the decoder
+ * blocks (dc1 .. dc6, dc22, dc42) are final: a data-parallel caller starts reducing that part of the gradient buffer on another
+ * stream while the encoder is still being differentiated (the exchange step that replaces DataParallel's reduce, train.py:577). */
+int seunet_net_backward_ev(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
+                           const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
+                           void* workspace, size_t workspace_bytes, seunet_stream_t s, void* decoder_done_event);
 
 /* ---- opt-in timing of the launch groups inside seunet_net_forward/backward (HIP events on the caller's
  * stream; process-wide, meant for one benchmarking thread at a time).  seunet_prof_report writes "tag<TAB>ms<TAB>count" lines and resets; it waits on

@@ -136,17 +136,29 @@ def registry(desc: _lib.NetDesc) -> List[Tuple[str, Tuple[int, ...]]]:
     return out
 
 
-def alloc_flat_grads(params, dead, device):
-    """One contiguous f32 buffer for the gradients of all LIVE parameters, in registry order, plus per-parameter
-    views of it (``None`` for the dead ``dc62`` block, which takes no space: the live gradients are back to back, so
-    ``ddp.allreduce_gradients`` reduces the buffer in place with ONE collective)."""
-    sizes = [0 if d else p.numel() for p, d in zip(params, dead)]
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-    grads, off = [], 0
-    for p, n, d in zip(params, sizes, dead):
-        grads.append(None if d else flat[off:off + n].view(p.shape))
-        off += n
-    return flat, grads
+def _is_decoder(name: str) -> bool:
+    return name.startswith("dc") and not name.startswith("dc0_")
+
+
+def alloc_flat_grads(params, dead, device, names=None):
+    """One contiguous f32 buffer for the gradients of all LIVE parameters plus per-parameter views of it (``None`` for the
+    dead ``dc62`` block, which takes no space).  Layout: the encoder blocks and the two heads first, the decoder blocks
+    (dc1 .. dc6, dc22, dc42) last -- the backward pass finishes the decoder's gradients first, so a data-parallel step
+    reduces the tail of the buffer while the encoder is still being differentiated and the head of it afterwards
+    (``ddp.GradSync``); without names: registry order.  Returns (flat, views in parameter order, first decoder element)."""
+    idx = list(range(len(params)))
+    if names is not None:
+        idx = [i for i in idx if not _is_decoder(names[i])] + [i for i in idx if _is_decoder(names[i])]
+    sizes = {i: (0 if dead[i] else params[i].numel()) for i in idx}
+    flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=device)
+    grads, off, split = [None] * len(params), 0, None
+    for i in idx:
+        if names is not None and split is None and _is_decoder(names[i]):
+            split = off
+        if not dead[i]:
+            grads[i] = flat[off:off + sizes[i]].view(params[i].shape)
+        off += sizes[i]
+    return flat, grads, (off if split is None else split)
 
 
 class _SEUNetFunction(torch.autograd.Function):
@@ -176,6 +188,7 @@ class _SEUNetFunction(torch.autograd.Function):
         ctx.dead = meta["dead"]
         ctx.loss_scale = float(meta.get("loss_scale", 1.0))
         ctx.overflow = meta.get("overflow")
+        ctx.names, ctx.grad_sync = meta.get("names"), meta.get("grad_sync")
         return pred0, pred1
 
     @staticmethod
@@ -193,12 +206,17 @@ class _SEUNetFunction(torch.autograd.Function):
             if ctx.loss_scale != 1.0:       # fp16 storage: keep the activation gradients inside half precision's range
                 g0, g1 = g0 * ctx.loss_scale, g1 * ctx.loss_scale
             # all live parameter gradients are views of ONE flat buffer (one RCCL all-reduce under data parallelism)
-            flat, grads = alloc_flat_grads(ctx.plist, ctx.dead, dev)
+            flat, grads, split = alloc_flat_grads(ctx.plist, ctx.dead, dev, ctx.names)
             garr = _lib.ptr_array(grads)
             parr = _lib.ptr_array(ctx.plist)
-            _lib.check(lib.seunet_net_backward(C.byref(ctx.desc), parr, g0.data_ptr(), g1.data_ptr(),
-                                               _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
-                                               ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr()), "net_backward")
+            sync = ctx.grad_sync if (ctx.grad_sync is not None and ctx.loss_scale == 1.0) else None
+            ev = sync.decoder_event() if sync is not None else None
+            _lib.check(lib.seunet_net_backward_ev(C.byref(ctx.desc), parr, g0.data_ptr(), g1.data_ptr(),
+                                                  _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
+                                                  ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr(),
+                                                  None if ev is None else ev.cuda_event), "net_backward")
+            if sync is not None:      # data parallel: decoder bucket on the side stream (already under way), the rest here
+                sync.exchange(flat, split, ev)
             if ctx.loss_scale != 1.0:
                 # a scaled activation gradient beyond half precision's range turns into inf / NaN in the flat buffer: such a step
                 # is dropped (zero gradients) and counted on the device, with no host synchronisation -- the caller reads
@@ -287,18 +305,19 @@ class SE_UNet(nn.Module):
                          self.conv_impl, self.negative_slope)
         level = {"ec1": 0, "ec2": 0, "ec3": 0, "ec33": 0, "dc5": 0, "dc6": 0, "ec4": 1, "ec5": 1, "ec6": 1, "ec63": 1, "dc3": 1,
                  "dc4": 1, "dc42": 1, "ec7": 2, "ec8": 2, "ec9": 2, "ec93": 2, "dc1": 2, "dc2": 2, "dc22": 2, "ec10": 3, "ec11": 3,
-                 "ec12": 3, "ec123": 3, "x33": 0, "x63": 1, "x93": 2}   # (x-branches: only when materialised, in_channel > 2)
+                 "ec12": 3, "ec123": 3, "x33": 0, "x63": 1, "x93": 2}   # (x-branches: raw / mean / rstd only)
         with torch.cuda.device(x.device):
             nbytes = lib.seunet_net_workspace_bytes(C.byref(desc))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             pred0 = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
             pred1 = torch.empty_like(pred0)
             plist = [p.detach().contiguous() for p in self.parameters()]
-            _lib.check(lib.seunet_net_forward(C.byref(desc), _lib.ptr_array(plist), x.data_ptr(), None, None, pred0.data_ptr(),
+            parr = _lib.ptr_array(plist)
+            _lib.check(lib.seunet_net_forward(C.byref(desc), parr, x.data_ptr(), None, None, pred0.data_ptr(),
                                               pred1.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr()), "net_forward")
 
             def read(name, which, buf, ch=None):
-                _lib.check(lib.seunet_net_read_tensor(C.byref(desc), ws.data_ptr(), nbytes, name.encode(), which, buf.data_ptr(),
+                _lib.check(lib.seunet_net_read_tensor(C.byref(desc), parr, ws.data_ptr(), nbytes, name.encode(), which, buf.data_ptr(),
                                                       ch, _lib.stream_ptr()), "net_read_tensor")
             out = {}
             for name in blocks:
@@ -342,6 +361,7 @@ class SE_UNet(nn.Module):
         meta = {"in_channel": self.in_channel, "n_classes": self.n_classes, "width_mult": self.width_mult,
                 "dtype": _lib.dtype_code(self.act_dtype), "conv_impl": self.conv_impl,
                 "negative_slope": float(self.negative_slope), "dead": self._dead, "loss_scale": float(self.loss_scale)}
+        meta["names"], meta["grad_sync"] = self._names, getattr(self, "grad_sync", None)
         if self.loss_scale != 1.0:
             if self.overflow_steps is None or self.overflow_steps.device != x.device:
                 self.overflow_steps = torch.zeros((), dtype=torch.int64, device=x.device)

@@ -109,8 +109,9 @@ PROTOTYPES = {
     "seunet_net_forward_capture": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, C.POINTER(C.c_void_p)]),
     "seunet_graph_launch": (_i, [_vp, _vp]),
     "seunet_graph_destroy": (_i, [_vp]),
-    "seunet_net_read_tensor": (_i, [C.POINTER(NetDesc), _vp, _sz, C.c_char_p, _i, _vp, _ip, _vp]),
+    "seunet_net_read_tensor": (_i, [C.POINTER(NetDesc), _pp, _vp, _sz, C.c_char_p, _i, _vp, _ip, _vp]),
     "seunet_net_backward": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _pp, _vp, _sz, _vp]),
+    "seunet_net_backward_ev": (_i, [C.POINTER(NetDesc), _pp, _vp, _vp, _vp, _vp, _pp, _vp, _sz, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

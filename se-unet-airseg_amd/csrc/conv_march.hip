@@ -24,7 +24,8 @@
 //     step that re-initialises it (the first MFMA of a row takes the bias vector / zero as its C operand, so nothing is
 //     ever zeroed), i.e. the epilogue of plane j runs under the MFMAs of plane j+3; gradient accumulation (+=) reads the
 //     old destination rows through a second LDS-DMA ring one step ahead;
-//   * InstanceNorm partial sums per lane in f32 (per plane, then across the march), f64 across lanes, one record per workgroup.
+//   * InstanceNorm partial sums per lane in f32 inside a plane, in f64 (LDS slots) across the march and across lanes, one
+//     record per workgroup.
 // One workgroup per CU: a 4 x 128^3 batch at 64 -> 32 channels is exactly 256 marches of 128 planes.
 #include "seunet_common.h"
 #include <utility>
@@ -99,7 +100,8 @@ template <int KS, int NGW, int RYW, int DIL, int MODE> struct MarchGeo {
   static constexpr int TOT = ITEMS + OLDN + STORES;                  // vector-memory operations per wave and step
   static constexpr int DUMP = MA_RING * PLB;                         // 1 KB landing area of the padding DMA instructions
   static constexpr int OLD = DUMP + 1024;                            // [2 slots][4 waves][RYW rows][32 voxels][32 B]
-  static constexpr int LDS = OLD + (MODE == 2 ? 2 * MA_NW * RYW * 1024 : 0);
+  static constexpr int STAT = OLD + (MODE == 2 ? 2 * MA_NW * RYW * 1024 : 0);   // forward: f64 march totals, [8 values][256 lanes]
+  static constexpr int LDS = STAT + (MODE == 0 ? 8 * 256 * 8 : 0);
   static_assert(HX <= MA_HXP, "row pitch");
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert((HYW - 1) * ROWB + 2 * 16 * VB < 65536, "fragment immediates must fit the 16-bit offset field");
@@ -258,12 +260,17 @@ conv_march_kernel(MarchArgs a) {
   for (int e = 0; e < 4; ++e) cinit[e] = (MODE == 0 && a.bias != nullptr) ? a.bias[co0 + 4 * g + e] : 0.f;
 
   // InstanceNorm sums of this lane's 4 channels: f32 inside a plane, f64 across the march
-  // (two-level f32: 16 values per plane, one add per plane into the march total -- 8 fewer registers than f64 totals, which
-  // the 216-weight-register forward variant does not have; the cross-lane / cross-workgroup sums are f64)
+  // f32 inside a plane (16 values per lane), f64 across the march: the march totals live in the LDS (one slot per lane and value;
+  // the 216-weight-register forward variant has no 16 registers for them), so that sums of f32 values are added in f64 all the
+  // way -- exact in practice, hence independent of how the planes are cut into marches (the batch size decides that)
   float s1[4], s2[4];
-  float S1[4], S2[4];
+  double* stot = reinterpret_cast<double*>(smem + Geo::STAT) + tid;     // value k at stot[k * 256]
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; S1[e] = 0.f; S2[e] = 0.f; }
+  for (int e = 0; e < 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if constexpr (MODE == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) stot[k * 256] = 0.0;
+  }
 
   const int yrow0 = y0 + rg * RYW;
   const bool okx0 = x0 + n16 < a.W, okx1 = x0 + 16 + n16 < a.W;
@@ -309,7 +316,11 @@ conv_march_kernel(MarchArgs a) {
   auto flush_stats = [&]() __attribute__((always_inline)) {
     if constexpr (MODE == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { S1[e] += s1[e]; S2[e] += s2[e]; s1[e] = 0.f; s2[e] = 0.f; }
+      for (int e = 0; e < 4; ++e) {
+        stot[e * 256] += (double)s1[e];
+        stot[(4 + e) * 256] += (double)s2[e];
+        s1[e] = 0.f; s2[e] = 0.f;
+      }
     }
   };
 
@@ -443,7 +454,7 @@ conv_march_kernel(MarchArgs a) {
       double* red = reinterpret_cast<double*>(smem);     // [4 waves][16 channels][2]
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        double t1 = (double)S1[e], t2 = (double)S2[e];
+        double t1 = stot[e * 256], t2 = stot[(4 + e) * 256];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) { t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
         if (n16 == 0) {

@@ -812,6 +812,39 @@ int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_
   return 0;
 }
 
+// diagnostic (seunet_net_read_tensor): the x-branch's raw values, recomputed by the same device function as the aggregation
+// epilogue uses (second_branch<true>: same expression, same contraction), written as NCDHW f32
+template <typename T>
+__global__ void __launch_bounds__(256)
+xbranch_values_kernel(const T* __restrict__ x_in, const float* __restrict__ w2x, int C, int xic, float* __restrict__ out, long long V,
+                      long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % (C / 8));
+    const long long nv = i / (C / 8);           // n * V + v
+    const long long n = nv / V, v = nv % V;
+    float wa[8], wb[8], in2[8], x2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wa[j] = w2x[(cg * 8 + j) * xic];
+      wb[j] = xic > 1 ? w2x[(cg * 8 + j) * xic + 1] : 0.f;
+    }
+    Pack8<T> px;
+    load8p(x_in + nv * 8, px);
+    unpack8(px, in2);
+    second_branch<true>(in2, wa, wb, x2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[(n * C + cg * 8 + j) * V + v] = x2[j];
+  }
+}
+int launch_xbranch_values(int dtype, const void* x_in, const float* w2, int C, int in_channel, float* out, Dims d, hipStream_t s) {
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2 && C % 8 == 0, "xbranch_values: bad argument");
+  const long long total = (long long)d.N * d.vox() * (C / 8);
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  SEUNET_DTYPE_SWITCH(dtype, xbranch_values_kernel<T><<<grid, 256, 0, s>>>((const T*)x_in, w2, C, in_channel, out, d.vox(), total));
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- two-branch aggregation block whose second branch is recomputed from the network input (XR) ---------------------
 int xbranch_moment_slots(Dims d) { return epi_partials(d); }
 

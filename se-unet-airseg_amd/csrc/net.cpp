@@ -507,6 +507,8 @@ struct Exec {
     return launch_conv_igemm(p.d.dtype, r.taps, o.dil, gsrc, r.cout, at(r.wp_d), nullptr, gd, nullptr, p.dims[lv], s);
   }
 
+  hipEvent_t decoder_done = nullptr;   // recorded once every gradient of the decoder blocks (dc1 .. dc6, dc22, dc42) is final
+
   int backward(const float* g_pred0, const float* g_pred1, const float* drop1, const float* drop2, float* const* grads) {
     if (int e = pack_all_weights(true)) return e;
     bool written[T_COUNT];
@@ -525,6 +527,11 @@ struct Exec {
       const OpDesc& o = kOps[i];
       const OpRes& r = p.op[i];
       const std::string n = o.name;
+      if (decoder_done && std::string(o.name) == "up0") {
+        // the walk is in reverse forward order: everything after up0 (the decoder) has been differentiated.  Its parameter
+        // gradients are final from here on (the heads' weights are not: the encoder blocks still add to dc0_0)
+        SEUNET_HIP(hipEventRecord(decoder_done, s));
+      }
       if (o.kind == OP_POOL || o.kind == OP_UP) {
         const int t = o.src[0];
         if (is_input(t)) continue;
@@ -724,8 +731,8 @@ int seunet_graph_destroy(void* graph) {
 // raw conv output of block `name` (before InstanceNorm; NCDHW f32, `channels` of them), 1 / 2 its per-(n, c) mean / rstd
 // ([N][C] f32), 3 the block's output tensor (for an aggregation block: after the x-branch was added; NCDHW f32).  Used by the
 // flip census (tests/flip_census.py): LeakyReLU sign / max-pool argmax disagreements with the float64 oracle.
-int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, size_t workspace_bytes, const char* name, int which,
-                           float* out, int* channels, seunet_stream_t s) {
+int seunet_net_read_tensor(const seunet_net_desc* desc, const float* const* params, const void* workspace, size_t workspace_bytes,
+                           const char* name, int which, float* out, int* channels, seunet_stream_t s) {
   SEUNET_CHECK(desc && workspace && name && out, "net_read_tensor: null argument");
   Plan p;
   if (int e = p.init(*desc)) return e;
@@ -737,9 +744,17 @@ int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, s
     const OpRes& r = p.op[i];
     const int lv = kT[o.dst].level;
     if (o.xname && std::string(o.xname) == name) {   // the raw-input branch of an aggregation block, when it is materialised (in_channel > 2)
-      SEUNET_CHECK(!p.fuse_x, "net_read_tensor: %s is recomputed inside the aggregation epilogue in this configuration (in_channel <= 2), it has no tensor", name);
       SEUNET_CHECK(which >= 0 && which <= 2, "net_read_tensor: which=%d is not stored for an x-branch", which);
       if (channels) *channels = r.cout;
+      if (which == 0 && p.fuse_x) {
+        // in_channel <= 2: the branch is recomputed inside the aggregation epilogue and leaves no tensor: recompute it here by the
+        // same device function, from the packed input in the workspace and the caller's weights
+        SEUNET_CHECK(params != nullptr, "net_read_tensor: the recomputed x-branch %s needs the parameter list", name);
+        const std::vector<ParamInfo> reg = build_registry(p.d);
+        const int wi = find_param(reg, std::string(name) + ".conv1.weight");
+        SEUNET_CHECK(wi >= 0 && params[wi], "net_read_tensor: no weight for %s", name);
+        return launch_xbranch_values(p.d.dtype, ws + p.feat[o.xsrc], params[wi], r.cout, p.d.in_channel, out, p.dims[lv], (hipStream_t)s);
+      }
       if (which == 0) return launch_unpack_cl(p.d.dtype, ws + r.raw2, r.cout, out, p.dims[lv], (hipStream_t)s);
       SEUNET_HIP(hipMemcpyAsync(out, ws + (which == 1 ? r.mean2 : r.rstd2), (size_t)p.d.batch * r.cout * 4, hipMemcpyDeviceToDevice, (hipStream_t)s));
       return 0;
@@ -758,9 +773,16 @@ int seunet_net_read_tensor(const seunet_net_desc* desc, const void* workspace, s
 int seunet_net_backward(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
                         const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
                         void* workspace, size_t workspace_bytes, seunet_stream_t s) {
+  return seunet_net_backward_ev(desc, params, g_pred0, g_pred1, drop1, drop2, grads, workspace, workspace_bytes, s, nullptr);
+}
+
+int seunet_net_backward_ev(const seunet_net_desc* desc, const float* const* params, const float* g_pred0,
+                           const float* g_pred1, const float* drop1, const float* drop2, float* const* grads,
+                           void* workspace, size_t workspace_bytes, seunet_stream_t s, void* decoder_done_event) {
   SEUNET_CHECK(g_pred0 && g_pred1 && grads, "net_backward: null tensor");
   Exec ex;
   if (int e = ex.setup(desc, params, workspace, workspace_bytes, (hipStream_t)s)) return e;
+  ex.decoder_done = reinterpret_cast<hipEvent_t>(decoder_done_event);
   return ex.backward(g_pred0, g_pred1, drop1, drop2, grads);
 }
 

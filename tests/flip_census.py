@@ -112,7 +112,7 @@ for impl, tag in ((0, "HIP MFMA (impl 0)"), (1, "HIP naive (impl 1)")):
     m = A.SE_UNet(2, 1, act_dtype="fp32", conv_impl=impl)
     m.load_state_dict(orc.deterministic_state_dict(2, 1, 1, 0))
     m = m.cuda().eval()
-    _, _, inter = m.forward_with_intermediates(b["image"].cuda(), BLOCKS)
+    _, _, inter = m.forward_with_intermediates(b["image"].cuda(), FO.LRELU_ORDER)
     raws = {n: inter[n]["raw"] for n in BLOCKS}
     pools = {POOLS[n]: inter[n]["out"] for n in POOLS}
     ge, gd = m(b["image"].cuda())

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 # order of the F.leaky_relu calls in OracleSEUNet.forward (one per block; x-branches have no materialised raw tensor in the HIP
-# path and keep the oracle's own signs)
+# path: forward_with_intermediates recomputes them with the epilogue.s device function)
 LRELU_ORDER = ["ec1", "ec2", "ec3", "ec33", "x33", "ec4", "ec5", "ec6", "ec63", "x63", "ec7", "ec8", "ec9", "ec93", "x93",
                "ec10", "ec11", "ec12", "ec123", "dc1", "dc2", "dc22", "dc3", "dc4", "dc42", "dc5", "dc6"]
 # F.max_pool3d calls: pool(e1), pool(x), pool(e3), pool(x1), pool(e5); the feature pools consume the outputs of these blocks

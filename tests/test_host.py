@@ -94,14 +94,20 @@ def _ddp_worker(rank, world, port, q):
     # (mid-list in registry order) takes no space, so the live gradients are back to back
     from seunet_amd.SE_UNet import alloc_flat_grads
     plist = list(m.parameters())
-    flat, grads = alloc_flat_grads(plist, m._dead, torch.device("cpu"))
+    names = [n for n, _ in m.named_parameters()]
+    # layout of the backward pass: encoder blocks + heads first, decoder blocks (whose gradients are final first) last
+    flat, grads, split = alloc_flat_grads(plist, m._dead, torch.device("cpu"), names)
+    dec = sum(p.numel() for n, p in m.named_parameters() if n.startswith("dc") and not n.startswith("dc0_") and not n.startswith("dc62."))
+    ok_layout = split == flat.numel() - dec and m.dc1.conv1.weight.numel() > 0
     flat.copy_(torch.arange(flat.numel(), dtype=torch.float32) * (rank + 1))
     for p, g in zip(plist, grads):
         p.grad = g
+    ok_layout = ok_layout and dict(zip(names, grads))["dc1.conv1.weight"].data_ptr() == flat[split:].data_ptr() \
+        and dict(zip(names, grads))["ec1.conv1.weight"].data_ptr() == flat.data_ptr()
     live = [p for n, p in m.named_parameters() if not n.startswith("dc62.")]
     zero_copy = ddp._flat_view([p.grad for p in m.parameters() if p.grad is not None]) is not None
     n = ddp.allreduce_gradients(m.parameters())
-    ok_flat = zero_copy and n == 1_520_314 - m.dc62.conv1.weight.numel() and torch.equal(flat, torch.arange(n, dtype=torch.float32) * 3)
+    ok_flat = ok_layout and zero_copy and n == 1_520_314 - m.dc62.conv1.weight.numel() and torch.equal(flat, torch.arange(n, dtype=torch.float32) * 3)
     # fallback path: separately allocated gradients
     for p in live:
         p.grad = torch.full_like(p, float(rank + 1))
