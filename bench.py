@@ -17,6 +17,7 @@ AdamW step (train.py:569,603).  Inputs are resident in HBM before the timed regi
   * `roofline`: the dominant launch group (chosen from a full per-launch table taken during warm-up), timed with HIP
     events on the launch stream inside the timed region;
   * `parity_mode` (N=1): ms/step of the fp32 activation mode, the one that meets north_star's 1e-3 tolerance;
+  * `fp16_mode` (N=1): ms/step with fp16 activation storage (same bytes / MFMA rate as bf16, 8 x smaller gradient error);
   * `cpu_baseline` (N=1): the CPU oracle (oracle/, torch fp32, the reference's op sequence), 1 warm-up + 3 timed steps.
 
 When `--gpus N > 1` and no torchrun environment is present, the parent process -- before anything touches the GPU --
@@ -424,6 +425,20 @@ def main():
                               "what": "same step with fp32 activation storage and fp32 MFMA: the mode the 1e-3 parity tests run in"}
         del m32, s32
         torch.cuda.empty_cache()
+        # ---- fp16 activation storage (BASELINE configs[4]'s dtype): the same bytes and MFMA rate as bf16 with three more
+        # mantissa bits -- 8 x smaller gradient error against float64 (profiles/r03_lowprec_attribution_32.md)
+        if args.dtype == "bf16":
+            m16 = make_model("fp16")
+            s16 = make_step(m16, make_opt(m16))
+            for _ in range(2):
+                s16()
+            dt4, per4, _ = timed(s16, k32)
+            out["fp16_mode"] = {"dtype": "fp16", "ms_per_step": 1e3 * dt4 / k32, "median_ms_per_step": statistics.median(per4),
+                                "value": voxels_step * k32 / dt4, "unit": "voxels/s", "steps": k32,
+                                "what": "same step with fp16 activation storage (static loss scale 65536): large-tensor gradient error "
+                                        "against float64 with the same discrete choices 6e-3 (bf16: 5e-2)"}
+            del m16, s16
+            torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
