@@ -142,6 +142,9 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--cpu-size", type=int, default=128)
     ap.add_argument("--dump-kernels", default="", help="write the full per-launch-group timing table (TSV) here")
+    ap.add_argument("--config", default="", choices=["", "window512"],
+                    help="window512: also time BASELINE configs[3] (one 512^3 volume, 128^3 windows, stride 64, 343 windows, forward "
+                         "only) and report it under `window512` (N=1)")
     return ap.parse_args()
 
 
@@ -425,6 +428,26 @@ def main():
                               "what": "same step with fp32 activation storage and fp32 MFMA: the mode the 1e-3 parity tests run in"}
         del m32, s32
         torch.cuda.empty_cache()
+        # ---- BASELINE configs[3]: sliding-window inference over one 512^3 volume (prediction.py:78-109)
+        if args.config == "window512":
+            from seunet_amd.sliding_window import auto_batch
+            mw = make_model(args.dtype).eval()
+            vol = torch.rand((1, args.in_channel, 512, 512, 512), device=dev)
+            A.sliding_window_predict(mw, vol[:, :, :192, :128, :128], batch=4, return_tensor=True)     # warm-up (4 windows)
+            times = []
+            for _ in range(2):
+                fence()
+                t0 = time.perf_counter()
+                res = A.sliding_window_predict(mw, vol, return_tensor=True)
+                fence()
+                times.append(time.perf_counter() - t0)
+            out["window512"] = {"seconds": min(times), "runs": times, "windows": 343, "batch": auto_batch(mw, dev),
+                                "output_voxels_per_s": 512 ** 3 / min(times), "window_voxels_per_s": 343 * 128 ** 3 / min(times),
+                                "dtype": args.dtype, "finite": bool(torch.isfinite(res).all()),
+                                "what": "one 512^3 two-channel volume resident in HBM -> overlap-averaged sigmoid volume (float64) in HBM; "
+                                        "decoder-head-only forward per window batch, device-side gather / accumulate / divide"}
+            del mw, vol, res
+            torch.cuda.empty_cache()
         # ---- fp16 activation storage (BASELINE configs[4]'s dtype): the same bytes and MFMA rate as bf16 with three more
         # mantissa bits -- 8 x smaller gradient error against float64 (profiles/r03_lowprec_attribution_32.md)
         if args.dtype == "bf16":

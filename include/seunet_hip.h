@@ -300,7 +300,9 @@ int seunet_net_param_info(const seunet_net_desc* desc, int index, char* name, in
 size_t seunet_net_workspace_bytes(const seunet_net_desc* desc);
 /* params: seunet_net_param_count device pointers in registry order.  x: NCDHW f32.  drop1/drop2: DropLayer
  * scale tensors [batch][24] / [batch][12] (NULL = eval mode identity).  pred0/pred1: [batch][1][d][h][w] f32 logits.
- * The workspace keeps everything the backward pass needs; pass the same buffer to seunet_net_backward. */
+ * The workspace keeps everything the backward pass needs; pass the same buffer to seunet_net_backward.
+ * pred0 == NULL: inference form (prediction.py:102-103 keeps only the decoder head's output): the encoder head, the side convs of
+ * the twelve encoder blocks and their level maps are not evaluated; pred1 is bit-identical; no backward pass may follow. */
 int seunet_net_forward(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
                        const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
                        seunet_stream_t s);

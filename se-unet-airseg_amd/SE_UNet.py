@@ -282,6 +282,7 @@ class SE_UNet(nn.Module):
         self._names = [n for n, _ in self.named_parameters()]
         self._dead = [n.startswith("dc62.") for n in self._names]
         self._registry_checked = False
+        self._arena = {}              # inference workspaces by (shape, dtype, device): predict_logits()
 
     def _check_registry(self, desc):
         if self._registry_checked:
@@ -336,6 +337,47 @@ class SE_UNet(nn.Module):
                 out[name] = rec
         return pred0, pred1, out
 
+    @torch.no_grad()
+    def predict_logits(self, x, out: Optional[torch.Tensor] = None):
+        """Inference form of the forward (prediction.py:102-103 ``p0, p = model(x)`` keeps only ``p``): the decoder head's logits
+        (B, 1, D, H, W), bit-identical to ``forward(x)[1]``; the encoder head, its twelve side convs and level maps are not
+        evaluated (``seunet_net_forward`` with pred0 = NULL).  No autograd graph.  The workspace is a per-shape arena owned by
+        the module and reused by every call (not a fresh 3-12 GB allocation per forward); ``release_arena()`` frees it."""
+        if not x.is_cuda:
+            raise RuntimeError("SE_UNet (HIP path) needs a tensor on an MI355X device; there is no CPU fallback")
+        if x.dim() != 5 or x.shape[1] != self.in_channel:
+            raise ValueError(f"expected input (B,{self.in_channel},D,H,W), got {tuple(x.shape)}")
+        lib = _lib.load()
+        x = x.contiguous().float()
+        b, _, d, h, w = x.shape
+        d1 = d2 = None
+        if self.training:                   # RNG order: dropout1 then dropout2 (SE_UNet.py:232-233); the first draw is still made
+            d1, d2 = self.dropout1.scale(b), self.dropout2.scale(b)
+            d1 = d1.reshape(b, 24).to(x.device, torch.float32).contiguous()
+            d2 = d2.reshape(b, 12).to(x.device, torch.float32).contiguous()
+        desc = make_desc(b, self.in_channel, self.n_classes, d, h, w, self.width_mult, _lib.dtype_code(self.act_dtype),
+                         self.conv_impl, self.negative_slope)
+        self._check_registry(desc)
+        key = (b, d, h, w, self.act_dtype, self.conv_impl, str(x.device))
+        with torch.cuda.device(x.device):
+            arena = self._arena.get(key)
+            if arena is None:
+                nbytes = lib.seunet_net_workspace_bytes(C.byref(desc))
+                if nbytes == 0:
+                    raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
+                self._arena.clear()         # one shape at a time: a window loop uses one (plus a ragged last batch)
+                arena = self._arena[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            if out is None:
+                out = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
+            plist = [p.detach().contiguous() for p in self.parameters()]
+            _lib.check(lib.seunet_net_forward(C.byref(desc), _lib.ptr_array(plist), x.data_ptr(), _lib.ptr(d1), _lib.ptr(d2), None,
+                                              out.data_ptr(), arena.data_ptr(), arena.numel(), _lib.stream_ptr()), "net_forward")
+            arena.record_stream(torch.cuda.current_stream(x.device))
+        return out
+
+    def release_arena(self):
+        self._arena.clear()
+
     def forward(self, x, drop_scales: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         """x: (B, in_channel, D, H, W) float, D/H/W multiples of 8 -> (pred0, pred1) logits.
         ``drop_scales`` optionally injects the two DropLayer scale tensors (B,24,1,1,1)/(B,12,1,1,1)."""
@@ -383,9 +425,10 @@ class CapturedForward:
     weights (``optimizer.step()``, ``load_state_dict``) are seen by the next replay; if a parameter tensor is REPLACED
     (``model.half()``, ``.to()``), the next call notices the changed pointers and records the graph again."""
 
-    def __init__(self, model: "SE_UNet", batch: int, spatial: Tuple[int, int, int]):
+    def __init__(self, model: "SE_UNet", batch: int, spatial: Tuple[int, int, int], decoder_only: bool = False):
         lib = _lib.load()
         self.model = model
+        self.decoder_only = decoder_only    # inference form: the encoder head is not evaluated (pred0 stays unwritten)
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("CapturedForward needs the model on an MI355X device (no CPU fallback)")
@@ -418,8 +461,8 @@ class CapturedForward:
         self._stream.wait_stream(cur)
         _lib.check(lib.seunet_init(self.device.index if self.device.index is not None else torch.cuda.current_device()), "init")
         with torch.cuda.stream(self._stream):
-            args = (C.byref(self.desc), parr, self.x.data_ptr(), d1, d2, self.pred0.data_ptr(), self.pred1.data_ptr(),
-                    self.ws.data_ptr(), self.ws_bytes, _lib.stream_ptr())
+            args = (C.byref(self.desc), parr, self.x.data_ptr(), d1, d2, None if self.decoder_only else self.pred0.data_ptr(),
+                    self.pred1.data_ptr(), self.ws.data_ptr(), self.ws_bytes, _lib.stream_ptr())
             _lib.check(lib.seunet_net_forward(*args), "net_forward")        # eager once: per-kernel one-time setup
             self._stream.synchronize()
             handle = C.c_void_p()

@@ -139,6 +139,7 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     w21[j] = p.w_side[C + c0 + j];
   }
   const float b20 = p.b_side[0], b21 = p.b_side[1], slope = p.slope;
+  const bool want_side = head.side_out != nullptr || head.level_map != nullptr;
   float hw0 = 0.f, hw1 = 0.f;
   if (head.level_map) {
     hw0 = head.head_w[0] * (head.drop ? head.drop[n * head.drop_stride + 0] : 1.f);
@@ -173,17 +174,19 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
 #pragma unroll
       for (int j = 0; j < 8; ++j) e[j] *= g2;
     }
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s0 += w20[j] * e[j]; s1 += w21[j] * e[j]; }
-    s0 = group_sum<LPV>(s0) + b20;
-    s1 = group_sum<LPV>(s1) + b21;
     store8(e_out + vi * C + c0, e);
-    if (cg == 0) {
-      if (head.side_out) { head.side_out[vi * 2] = s0; head.side_out[vi * 2 + 1] = s1; }
-      if (head.level_map) {
-        const float t = hw0 * s0 + hw1 * s1;
-        head.level_map[vi] = head.level_accumulate ? head.level_map[vi] + t : t;
+    if (want_side) {     // (block-uniform; off for the encoder blocks of an inference forward that discards the encoder head)
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s0 += w20[j] * e[j]; s1 += w21[j] * e[j]; }
+      s0 = group_sum<LPV>(s0) + b20;
+      s1 = group_sum<LPV>(s1) + b21;
+      if (cg == 0) {
+        if (head.side_out) { head.side_out[vi * 2] = s0; head.side_out[vi * 2 + 1] = s1; }
+        if (head.level_map) {
+          const float t = hw0 * s0 + hw1 * s1;
+          head.level_map[vi] = head.level_accumulate ? head.level_map[vi] + t : t;
+        }
       }
     }
   }

@@ -344,10 +344,13 @@ struct Exec {
     sp.slope = p.d.negative_slope;
     return sp;
   }
+  bool skip_enc_head = false;   // inference (prediction.py:102-103 discards pred0): the encoder head and its side maps are not evaluated
+
   SseHead sse_head(const OpDesc& o, const float* drop1, const float* drop2, bool first_of_level) const {
     SseHead h{};
     const int lv = kT[o.dst].level;
     h.side_out = nullptr;
+    if (o.head == 0 && skip_enc_head) return h;     // (no level map: the epilogue skips the side conv altogether)
     h.level_map = fat(p.lvl[o.head][lv]);
     h.level_accumulate = first_of_level ? 0 : 1;
     h.head_w = (o.head == 0 ? P("dc0_0.weight") : P("dc0_1.weight")) + 2 * o.m;
@@ -395,6 +398,7 @@ struct Exec {
   }
 
   int forward(const float* x, const float* drop1, const float* drop2, float* pred0, float* pred1) {
+    skip_enc_head = pred0 == nullptr;
     if (int e = pack_all_weights(false)) return e;
     mark("pack_input");
     if (int e = launch_pack_input(p.d.dtype, x, p.d.in_channel, at(p.feat[T_X0]), p.dims[0], s)) return e;
@@ -459,7 +463,8 @@ struct Exec {
     const float* enc[4] = {fat(p.lvl[0][0]), fat(p.lvl[0][1]), fat(p.lvl[0][2]), fat(p.lvl[0][3])};
     const float* dec[3] = {fat(p.lvl[1][0]), fat(p.lvl[1][1]), fat(p.lvl[1][2])};
     mark("head_fwd");
-    if (int e = launch_head_fwd(enc, 4, P("dc0_0.bias"), pred0, p.dims[0], s)) return e;
+    if (!skip_enc_head)
+      if (int e = launch_head_fwd(enc, 4, P("dc0_0.bias"), pred0, p.dims[0], s)) return e;
     if (int e = launch_head_fwd(dec, 3, P("dc0_1.bias"), pred1, p.dims[0], s)) return e;
     mark("outside");
     return 0;
@@ -668,7 +673,7 @@ size_t seunet_net_workspace_bytes(const seunet_net_desc* desc) {
 int seunet_net_forward(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
                        const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
                        seunet_stream_t s) {
-  SEUNET_CHECK(x && pred0 && pred1, "net_forward: null tensor");
+  SEUNET_CHECK(x && pred1, "net_forward: null tensor");
   Exec ex;
   if (int e = ex.setup(desc, params, workspace, workspace_bytes, (hipStream_t)s)) return e;
   return ex.forward(x, drop1, drop2, pred0, pred1);
@@ -685,7 +690,7 @@ struct NetGraph {
 int seunet_net_forward_capture(const seunet_net_desc* desc, const float* const* params, const float* x, const float* drop1,
                                const float* drop2, float* pred0, float* pred1, void* workspace, size_t workspace_bytes,
                                seunet_stream_t s, void** graph_out) {
-  SEUNET_CHECK(x && pred0 && pred1 && graph_out, "net_forward_capture: null argument");
+  SEUNET_CHECK(x && pred1 && graph_out, "net_forward_capture: null argument");
   SEUNET_CHECK(s != nullptr, "net_forward_capture: stream capture needs a stream other than the null stream");
   SEUNET_CHECK(!prof_on(), "net_forward_capture: switch the launch-group timer off before capturing");
   *graph_out = nullptr;

@@ -70,7 +70,7 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
         cap = None
         if graph and len(pos) >= 2 * batch:
             from .SE_UNet import CapturedForward
-            cap = CapturedForward(model, batch, (cube, cube, cube))
+            cap = CapturedForward(model, batch, (cube, cube, cube), decoder_only=True)
         for i in range(0, len(pos), batch):
             chunk = pos[i:i + batch]
             use_cap = cap is not None and len(chunk) == batch
@@ -79,8 +79,9 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
                 sub = chunk[j:j + max_call]
                 arr = _lib.int_array([v for p in sub for v in p])
                 _lib.check(lib.seunet_window_gather(x.data_ptr(), C_, X, Y, Z, cube, len(sub), arr, xin[j:].data_ptr(), st), "window_gather")
-            _, p = cap() if use_cap else model(xin)     # logits of the decoder head (prediction.py:103 `p0, p = model(...)`)
-            p = p.contiguous()
+            # logits of the decoder head (prediction.py:103 `p0, p = model(...)` keeps only p): the inference form of the
+            # forward, which does not evaluate the encoder head
+            p = cap()[1] if use_cap else model.predict_logits(xin)
             for j in range(0, len(chunk), max_call):
                 sub = chunk[j:j + max_call]
                 arr = _lib.int_array([v for q in sub for v in q])

@@ -730,6 +730,30 @@ def test_data_parallel_two_gpus_equal_one_gpu_batch2_rccl(A, orc, overlap):
     _run_dp_equivalence(A, orc, "nccl", overlap=overlap)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_inference_forward_skips_encoder_head_bit_identical(A, orc, dtype):
+    """prediction.py:102-103 keeps only the decoder head's logits: ``predict_logits`` (seunet_net_forward with pred0 = NULL)
+    evaluates neither the encoder head nor the side convs / level maps of the twelve encoder blocks, and must return the very
+    bits of ``forward(x)[1]`` -- in eval mode and, with the same CPU-generator state, under model.train() (the validation
+    loops run that way, train.py:632); repeated calls reuse one workspace arena."""
+    m = build(A, orc, 2, dtype)
+    x = orc.synthetic_batch(2, (64, 64, 64), 2, seed=23)["image"].cuda()
+    with torch.no_grad():
+        q = m(x)[1]
+    p = m.predict_logits(x)
+    p2 = m.predict_logits(x)
+    assert torch.equal(p, q) and torch.equal(p2, q) and len(m._arena) == 1
+    m.train()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        qt = m(x)[1]
+    torch.manual_seed(5)
+    pt = m.predict_logits(x)
+    assert torch.equal(pt, qt) and not torch.equal(pt, q)
+    m.release_arena()
+    assert not m._arena
+
+
 def _window_worker(rank, world, port, q):
     import os as _os
     import sys as _sys
