@@ -42,9 +42,11 @@ def draw_augmentation() -> int:
     (``random.random() > 0.5`` -> left, else right, :61-66)."""
     flipid, rot = None, None
     if random.random() > 0.5:
-        flipid = np.array([np.random.randint(2), np.random.randint(2), np.random.randint(2)]) * 2 - 1
-        while (flipid == [1, 1, 1]).all():
-            flipid = np.array([np.random.randint(2), np.random.randint(2), np.random.randint(2)]) * 2 - 1
+        while True:                                   # three numpy draws per attempt (axis order z, y, x), until some axis flips
+            bits = [int(np.random.randint(2)) for _ in range(3)]
+            if any(b == 0 for b in bits):             # bit 0 -> step -1 (that axis is reversed), bit 1 -> step +1
+                break
+        flipid = np.array([2 * b - 1 for b in bits])
     if random.random() > 0.5:
         rot = "left" if random.random() > 0.5 else "right"
     return aug_code(flipid, rot)

@@ -147,21 +147,20 @@ class MetricSums:
 
 
 def branch_detected_calculation(pred, label_parsing, label_skeleton, thresh=0.8, sums: "MetricSums" = None):
-    """metrics.py:14-29 -> (total_branch_num, detected_branch_num, detected_branch_ratio)."""
+    """metrics.py:14-29 -> (total_branch_num, detected_branch_num, detected_branch_ratio), from the per-branch skeleton voxel
+    counts the device histogram returns: a branch counts as detected when the prediction covers at least ``thresh`` of its
+    skeleton voxels.  The reference divides two bincounts (the predicted one zero-padded to the labelled one's length) and
+    compares the ratio with ``thresh``; a branch id without skeleton voxels gives 0/0 = NaN there, which never passes."""
     s = sums or MetricSums(pred, None, label_skeleton, label_parsing)
-    label_branch_bincount = s.branch_label[1:s.max_id + 1]
-    total_branch_num = label_branch_bincount.shape[0]
-    nz = np.nonzero(s.branch_pred[1:])[0]
-    pred_branch_bincount = s.branch_pred[1:(int(nz[-1]) + 2 if nz.size else 1)]          # np.bincount stops at the largest id present
-    if total_branch_num != pred_branch_bincount.shape[0]:
-        lack_num = total_branch_num - pred_branch_bincount.shape[0]
-        pred_branch_bincount = np.concatenate((pred_branch_bincount, np.zeros(lack_num)))
-    with np.errstate(divide="ignore", invalid="ignore"):
-        branch_ratio_array = pred_branch_bincount / label_branch_bincount
-    branch_ratio_array = np.where(branch_ratio_array >= thresh, 1, 0)
-    detected_branch_num = np.count_nonzero(branch_ratio_array)
-    detected_branch_ratio = round((detected_branch_num * 100) / total_branch_num, 2)
-    return total_branch_num, detected_branch_num, detected_branch_ratio
+    n_branches = int(s.max_id)                       # ids 1 .. max_id (np.bincount's length follows the largest id present)
+    in_label = np.asarray(s.branch_label[1:n_branches + 1], dtype=np.float64)
+    covered = np.zeros(n_branches, dtype=np.float64)
+    have = np.asarray(s.branch_pred[1:n_branches + 1], dtype=np.float64)
+    covered[:have.shape[0]] = have
+    frac = np.divide(covered, in_label, out=np.full(n_branches, -1.0), where=in_label > 0)    # (0/0: a miss, like NaN >= thresh)
+    hit = frac >= thresh
+    detected = int(np.count_nonzero(hit))
+    return n_branches, detected, round(detected * 100 / n_branches, 2)
 
 
 def dice_coefficient_score_calculation(pred, label, smooth=1e-5, sums: "MetricSums" = None):
