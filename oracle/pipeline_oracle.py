@@ -166,3 +166,71 @@ def crop_batch(img: np.ndarray, starts, codes, cube: int, label=None, weight=Non
         if skeleton is not None:
             out["skel"].append(apply_code(skeleton[sl], code).astype(np.float32)[None])
     return {k: np.stack(v) for k, v in out.items() if v}
+
+
+# ---- the random plans of AirwayHMData.__getitem__ (stage 2) and AirwayHMData3.__getitem__ (stage 3) ---------------------
+def _guided_start(loc, origin_size, cube):
+    """skeleton_sample / small_airway_sample / hard_sample / *_sample_wg (data.py:85-252): one randint picks the voxel, one
+    randint per axis places the origin in [max(0, v - cube//2), v + cube//2), origins past the end are clamped."""
+    k = np.random.randint(len(loc[0]))
+    start = [np.random.randint(max(0, loc[a][k] - cube // 2), loc[a][k] + cube // 2) for a in range(3)]
+    for a in range(3):
+        if start[a] + cube > origin_size[a]:
+            start[a] = origin_size[a] - cube
+    return tuple(int(v) for v in start)
+
+
+def _uniform_start(origin_size, cube):
+    """random_sample / random_sample_wg (data.py:159-172, 240-252)."""
+    return tuple(int(np.random.randint(0, origin_size[a] - cube)) for a in range(3))
+
+
+def _augment_codes(batch_size, aug_flag):
+    codes = []
+    for _ in range(batch_size):
+        flipid, rot = None, None
+        if aug_flag == 1:
+            if random.random() > 0.5:
+                flipid = np.array([np.random.randint(2), np.random.randint(2), np.random.randint(2)]) * 2 - 1
+                while (flipid == [1, 1, 1]).all():
+                    flipid = np.array([np.random.randint(2), np.random.randint(2), np.random.randint(2)]) * 2 - 1
+            if random.random() > 0.5:
+                rot = "left" if random.random() > 0.5 else "right"
+        codes.append(aug_code(flipid, rot))
+    return codes
+
+
+def draw_stage2_plan(shape, batch_size, loc_skeleton, loc_small, cube=128, hard_ratio=0.4, aug_flag=1) -> Dict:
+    """AirwayHMData.__getitem__ (data.py:359-408): exponent draw (:388), then ``crop`` (:301-324) with ``hard_sample`` (:120-157)
+    / ``random_sample`` (:159-172), then one ``augment`` per crop (:351-357)."""
+    u = np.random.random()
+    starts = []
+    for _ in range(batch_size):
+        if np.random.random() < hard_ratio:
+            if np.random.random() > 0.5 and len(loc_skeleton[0]) > 0:
+                starts.append(_guided_start(loc_skeleton, shape, cube))
+            elif len(loc_small[0]) > 0:
+                starts.append(_guided_start(loc_small, shape, cube))
+            else:
+                starts.append(_uniform_start(shape, cube))
+        else:
+            starts.append(_uniform_start(shape, cube))
+    return {"u": float(u), "starts": starts, "codes": _augment_codes(batch_size, aug_flag)}
+
+
+def draw_stage3_plan(shape, batch_size, loc_skeleton, loc_small, loc_break, cube=128, hard_ratio=0.8, break_ratio=0.625,
+                     aug_flag=1) -> Dict:
+    """AirwayHMData3.__getitem__ (data.py:546-584) with ``crop`` (:449-491)."""
+    u = np.random.random()
+    starts = []
+    for _ in range(batch_size):
+        if np.random.random() < hard_ratio:
+            if np.random.random() < break_ratio and len(loc_break[0]) != 0:
+                starts.append(_guided_start(loc_break, shape, cube))
+            elif np.random.random() < 0.5:
+                starts.append(_guided_start(loc_small, shape, cube))
+            else:
+                starts.append(_guided_start(loc_skeleton, shape, cube))
+        else:
+            starts.append(_uniform_start(shape, cube))
+    return {"u": float(u), "starts": starts, "codes": _augment_codes(batch_size, aug_flag)}

@@ -65,6 +65,77 @@ def draw_stage1_plan(shape: Sequence[int], batch_size: int, cube: int = 128, aug
     return {"u": u, "starts": starts, "codes": codes}
 
 
+def _loc_len(loc) -> int:
+    return int(len(loc[0]))
+
+
+def _start_near(loc, shape: Sequence[int], cube: int) -> Tuple[int, int, int]:
+    """The crop origin of the reference's location-guided samplers (``skeleton_sample`` / ``small_airway_sample`` /
+    ``hard_sample`` / ``*_sample_wg``, data.py:85-252): one ``np.random.randint(len(loc[0]))`` picks a voxel of the candidate
+    list, then per axis one ``np.random.randint(max(0, v - cube // 2), v + cube // 2)``; an origin whose cube would leave the
+    volume is moved back to ``dim - cube``."""
+    k = int(np.random.randint(_loc_len(loc)))
+    half = cube // 2
+    start = []
+    for ax in range(3):
+        v = int(loc[ax][k])
+        start.append(int(np.random.randint(max(0, v - half), v + half)))
+    return tuple(min(st, int(shape[ax]) - cube) if st + cube > int(shape[ax]) else st for ax, st in enumerate(start))
+
+
+def _start_uniform(shape: Sequence[int], cube: int) -> Tuple[int, int, int]:
+    """``random_sample`` (data.py:159-172): three ``np.random.randint(0, dim - cube)`` (exclusive upper bound)."""
+    return tuple(int(np.random.randint(0, int(shape[ax]) - cube)) for ax in range(3))
+
+
+def draw_stage2_plan(shape: Sequence[int], batch_size: int, loc_skeleton, loc_small, cube: int = 128, hard_ratio: float = 0.4,
+                     aug_flag: int = 1) -> Dict:
+    """The random choices of one ``AirwayHMData.__getitem__`` (data.py:301-324, 359-408) in its draw order: the weight exponent
+    ``np.random.random()`` (:388); then per crop (``crop``, :301-324) ``np.random.random() < hard_ratio`` -> ``hard_sample``
+    (:120-157: ``np.random.random() > 0.5`` and a non-empty missed-skeleton list -> that list, else the small-airway list if
+    non-empty, else a uniform origin), otherwise ``random_sample``; then per crop one ``augment``.  ``loc_skeleton`` /
+    ``loc_small``: the (z, y, x) index triples ``np.where(skeleton * (1 - pred))`` / ``np.where(dis * skeleton < 2)`` of the case
+    (:305-306; any indexable triple: numpy arrays or tensors).  ``kinds``: 'skeleton' | 'small' | 'random' per crop."""
+    u = float(np.random.random())
+    starts, kinds = [], []
+    for _ in range(batch_size):
+        if np.random.random() < hard_ratio:
+            pick_skel = np.random.random() > 0.5           # (drawn whether or not the list is empty: `and` evaluates it first)
+            if pick_skel and _loc_len(loc_skeleton) > 0:
+                starts.append(_start_near(loc_skeleton, shape, cube)); kinds.append("skeleton")
+            elif _loc_len(loc_small) > 0:
+                starts.append(_start_near(loc_small, shape, cube)); kinds.append("small")
+            else:
+                starts.append(_start_uniform(shape, cube)); kinds.append("random")
+        else:
+            starts.append(_start_uniform(shape, cube)); kinds.append("random")
+    codes = [draw_augmentation() if aug_flag == 1 else 0 for _ in range(batch_size)]
+    return {"u": u, "starts": starts, "codes": codes, "kinds": kinds}
+
+
+def draw_stage3_plan(shape: Sequence[int], batch_size: int, loc_skeleton, loc_small, loc_break, cube: int = 128,
+                     hard_ratio: float = 0.8, break_ratio: float = 0.625, aug_flag: int = 1) -> Dict:
+    """The random choices of one ``AirwayHMData3.__getitem__`` (data.py:449-491, 546-584): the weight exponent (:566); per
+    crop ``np.random.random() < hard_ratio`` -> (``np.random.random() < break_ratio`` and a non-empty break list -> a break
+    sample, else ``np.random.random() < 0.5`` -> small-airway sample, else missed-skeleton sample), otherwise a uniform
+    origin; then per crop one ``augment``.  ``loc_break``: the saved ``np.where(br_skel == 1)`` triple (weight_br.py:171)."""
+    u = float(np.random.random())
+    starts, kinds = [], []
+    for _ in range(batch_size):
+        if np.random.random() < hard_ratio:
+            take_break = np.random.random() < break_ratio
+            if take_break and _loc_len(loc_break) != 0:
+                starts.append(_start_near(loc_break, shape, cube)); kinds.append("break")
+            elif np.random.random() < 0.5:
+                starts.append(_start_near(loc_small, shape, cube)); kinds.append("small")
+            else:
+                starts.append(_start_near(loc_skeleton, shape, cube)); kinds.append("skeleton")
+        else:
+            starts.append(_start_uniform(shape, cube)); kinds.append("random")
+    codes = [draw_augmentation() if aug_flag == 1 else 0 for _ in range(batch_size)]
+    return {"u": u, "starts": starts, "codes": codes, "kinds": kinds}
+
+
 def _dev(t, name, dtypes):
     if t is None:
         return None
@@ -152,3 +223,82 @@ class CropSegDataGPU:
     def sample(self) -> Dict[str, torch.Tensor]:
         plan = draw_stage1_plan(self.img.shape, self.batch_size, self.cube, self.aug_flag)
         return crop_batch(self.img, plan["starts"], self.cube, self.label, self.weight, None, plan["codes"], plan["u"], f64_math=False)
+
+
+def _trend(xs) -> float:
+    return float(xs[-1] - xs[-2]) if len(xs) > 1 else 0.0
+
+
+class AirwayHMDataGPU:
+    """Stage-2 sampler with the interface of the reference's ``AirwayHMData`` minus the file IO (data.py:254-408): the case
+    volumes are resident on the GPU (HU int16 = file value - 1024, uint8 label, float16 LIB weight), the two candidate lists
+    of the hard-mining samplers (``loc_skeleton`` = where(skeleton * (1 - pred)), ``loc_small`` = where(EDT(label) * skeleton
+    < 2), data.py:305-306) are computed once per case by the caller; ``sample()`` = one ``__getitem__`` + the step's
+    ``.float().cuda()`` / transpose / cat (train.py:416-426).  ``hard_ratio`` and ``update_scheduler`` follow :273-283,326-349."""
+
+    def __init__(self, img, label, weight, loc_skeleton, loc_small, batch_size: int, aug_flag: int = 1, cube: int = 128):
+        self.img, self.label, self.weight = img, label, weight
+        self.loc_skeleton, self.loc_small = loc_skeleton, loc_small
+        self.batch_size, self.aug_flag, self.cube = batch_size, aug_flag, cube
+        self.random_ratio, self.hard_ratio = 0.6, 0.4
+        self.decay_step, self.decay_rate, self.max_hard_ratio, self.min_hard_ratio = 5, 0.05, 0.8, 0.2
+
+    def sample(self) -> Dict[str, torch.Tensor]:
+        plan = draw_stage2_plan(self.img.shape, self.batch_size, self.loc_skeleton, self.loc_small, self.cube, self.hard_ratio,
+                                self.aug_flag)
+        out = crop_batch(self.img, plan["starts"], self.cube, self.label, self.weight, None, plan["codes"], plan["u"])
+        out["kinds"] = plan["kinds"]
+        return out
+
+    def update_scheduler(self, epoch, val_loss_random_list, val_loss_hard_list, val_td_list, val_bd_list):
+        """data.py:326-349: every ``decay_step`` epochs move ``hard_ratio`` by ``decay_rate`` towards more hard mining when the hard
+        crops lose more than the random ones or the tree metrics fell, towards less when they agree and the tree improves."""
+        if epoch % self.decay_step != 0 or epoch == 0:
+            return
+        window = min(3, len(val_loss_random_list))
+        diff = float(np.mean(val_loss_random_list[-window:]) - np.mean(val_loss_hard_list[-window:]))
+        td, bd = _trend(val_td_list), _trend(val_bd_list)
+        if diff > 0.04 or td < 0 or bd < 0:
+            self.hard_ratio = min(self.max_hard_ratio, self.hard_ratio + self.decay_rate)
+        elif diff < 0.02 and td >= 0 and bd >= 0:
+            self.hard_ratio = max(self.min_hard_ratio, self.hard_ratio - self.decay_rate)
+        elif diff > 0.05 or td < -1 or bd < -1:          # (unreachable after the first test, kept for the reference's order)
+            self.hard_ratio = max(self.min_hard_ratio, self.hard_ratio - self.decay_rate)
+
+
+class AirwayHMData3GPU:
+    """Stage-3 sampler (reference ``AirwayHMData3``, data.py:410-584): as stage 2 plus the break-point list ``loc_break`` and
+    the skeleton crop; the weight volume handed over is already ``LIB + 0.6 * break weight`` in float16 (:553-557)."""
+
+    def __init__(self, img, label, weight, skeleton, loc_skeleton, loc_small, loc_break, batch_size: int, aug_flag: int = 1,
+                 cube: int = 128):
+        self.img, self.label, self.weight, self.skeleton = img, label, weight, skeleton
+        self.loc_skeleton, self.loc_small, self.loc_break = loc_skeleton, loc_small, loc_break
+        self.batch_size, self.aug_flag, self.cube = batch_size, aug_flag, cube
+        self.hard_ratio, self.break_ratio = 0.8, 0.625
+        self.min_hard_ratio, self.max_hard_ratio, self.min_break_ratio, self.max_break_ratio = 0.5, 0.9, 0.2, 0.8
+        self.decay_rate, self.decay_step = 0.05, 1
+
+    def sample(self) -> Dict[str, torch.Tensor]:
+        plan = draw_stage3_plan(self.img.shape, self.batch_size, self.loc_skeleton, self.loc_small, self.loc_break, self.cube,
+                                self.hard_ratio, self.break_ratio, self.aug_flag)
+        out = crop_batch(self.img, plan["starts"], self.cube, self.label, self.weight, self.skeleton, plan["codes"], plan["u"])
+        out["kinds"] = plan["kinds"]
+        return out
+
+    def update_scheduler(self, epoch, val_loss_random_list, val_loss_hard_list, val_td_list, val_bd_list):
+        """data.py:493-534: ``hard_ratio`` as in stage 2 (every epoch here); ``break_ratio`` up when either tree metric fell, down
+        when both rose."""
+        if epoch % self.decay_step != 0 or epoch == 0:
+            return
+        window = min(3, len(val_loss_random_list))
+        diff = float(np.mean(val_loss_random_list[-window:]) - np.mean(val_loss_hard_list[-window:]))
+        td, bd = _trend(val_td_list), _trend(val_bd_list)
+        if diff > 0.04 or td < 0 or bd < 0:
+            self.hard_ratio = min(self.max_hard_ratio, self.hard_ratio + self.decay_rate)
+        elif diff < 0.02 and td >= 0 and bd >= 0:
+            self.hard_ratio = max(self.min_hard_ratio, self.hard_ratio - self.decay_rate)
+        if td < 0 or bd < 0:
+            self.break_ratio = min(self.max_break_ratio, self.break_ratio + self.decay_rate)
+        elif td > 0 and bd > 0:
+            self.break_ratio = max(self.min_break_ratio, self.break_ratio - self.decay_rate)

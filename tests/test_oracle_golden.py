@@ -221,6 +221,75 @@ def test_pipeline_oracle_matches_reference_helpers_fixture(golden_dir):
             assert A.aug_code(f, r) == po.aug_code(f, r)
 
 
+def _hm_locs(g):
+    """The candidate lists of the hard-mining samplers as AirwayHMData.crop / AirwayHMData3.crop build them (data.py:305-306,
+    454-457): small-airway voxels from the label's Euclidean distance transform, skeleton voxels the previous stage missed."""
+    from scipy import ndimage
+    label, skeleton, pred = g["label"], g["skeleton"], g["pred"]
+    dis = ndimage.distance_transform_edt(label)
+    return np.where(skeleton * (1 - pred)), np.where((dis * skeleton) < 2), tuple(g["br_skel"])
+
+
+def test_stage23_sampler_plans_match_reference_samplers_fixture(golden_dir):
+    """The stage-2 / stage-3 draw order (AirwayHMData / AirwayHMData3 ``__getitem__``: data.py:359-408, 546-584 with ``crop``
+    :301-324, :449-491 and the samplers :85-252) restated in oracle/pipeline_oracle.py against batches produced by the
+    reference's OWN crop / process_img / augment methods and sampler functions (oracle/make_golden_pipeline_hm.py), bit-exact;
+    and the product package's host-side plans draw the same numbers in the same order."""
+    import random
+    import pipeline_oracle as po
+    import seunet_amd as A
+    g = _load(golden_dir, "pipeline_hm_known.npz")
+    img, label, skeleton, cube, b = g["img"], g["label"], g["skeleton"], int(g["cube"]), int(g["batch"])
+    loc_skel, loc_small, loc_break = _hm_locs(g)
+    assert len(loc_skel[0]) > 0 and len(loc_small[0]) > 0 and len(loc_break[0]) > 0
+    kinds = set()
+    for seed in (1, 2):
+        for stage in (2, 3):
+            def plan_of(mod):
+                random.seed(300 + seed); np.random.seed(400 + seed)
+                if stage == 2:
+                    return mod.draw_stage2_plan(img.shape, b, loc_skel, loc_small, cube)
+                return mod.draw_stage3_plan(img.shape, b, loc_skel, loc_small, loc_break, cube)
+            plan = plan_of(po)
+            w = g["weight16"] if stage == 2 else g["weight3"]
+            out = po.crop_batch(img, plan["starts"], plan["codes"], cube, label, w, skeleton if stage == 3 else None, plan["u"])
+            for k in ("data", "label", "weight") + (("skel",) if stage == 3 else ()):
+                np.testing.assert_array_equal(out[k], g[f"s{stage}_{seed}_{k}"], err_msg=f"stage {stage} seed {seed} {k}")
+            mine = plan_of(A)
+            assert mine["u"] == plan["u"] and mine["starts"] == plan["starts"] and mine["codes"] == plan["codes"]
+            kinds |= set(mine["kinds"])
+    assert {"random", "small", "skeleton", "break"} <= kinds          # every branch of both samplers was taken
+    # empty candidate lists: stage 2 falls back to the small-airway list, then to a uniform origin (hard_sample, data.py:124-136)
+    empty = (np.array([], dtype=np.int64),) * 3
+    random.seed(1); np.random.seed(2)
+    a = po.draw_stage2_plan(img.shape, 8, empty, empty, cube, hard_ratio=1.0)
+    random.seed(1); np.random.seed(2)
+    m = A.draw_stage2_plan(img.shape, 8, empty, empty, cube, hard_ratio=1.0)
+    assert m["starts"] == a["starts"] and set(m["kinds"]) == {"random"}
+
+
+def test_stage23_schedulers_follow_the_reference_rules():
+    """update_scheduler of the two hard-mining datasets (data.py:326-349, 493-534) on hand-made validation histories."""
+    import seunet_amd as A
+    ds = A.AirwayHMDataGPU(None, None, None, None, None, 4)
+    ds.update_scheduler(3, [0.5], [0.4], [1, 2], [1, 2])           # not a multiple of decay_step: unchanged
+    assert ds.hard_ratio == 0.4
+    ds.update_scheduler(5, [0.5, 0.5], [0.4, 0.4], [1, 2], [1, 2])   # random crops lose 0.1 more: more hard mining
+    assert ds.hard_ratio == pytest.approx(0.45)
+    ds.update_scheduler(10, [0.40], [0.39], [1, 2], [1, 2])          # agree, tree improving: less
+    assert ds.hard_ratio == pytest.approx(0.40)
+    ds.hard_ratio = 0.8
+    ds.update_scheduler(15, [0.5], [0.4], [2, 1], [1, 2])            # capped at max_hard_ratio
+    assert ds.hard_ratio == 0.8
+    d3 = A.AirwayHMData3GPU(None, None, None, None, None, None, None, 4)
+    d3.update_scheduler(1, [0.5], [0.4], [2, 1], [1, 2])             # TD fell: more hard, more break
+    assert d3.hard_ratio == pytest.approx(0.85) and d3.break_ratio == pytest.approx(0.675)
+    d3.update_scheduler(2, [0.40], [0.39], [1, 2], [1, 2])           # both rose: less of both
+    assert d3.hard_ratio == pytest.approx(0.80) and d3.break_ratio == pytest.approx(0.625)
+    d3.update_scheduler(0, [0.9], [0.1], [2, 1], [2, 1])             # epoch 0: never
+    assert d3.hard_ratio == pytest.approx(0.80)
+
+
 def test_metrics_oracle_matches_reference_metrics_module_fixture(golden_dir):
     """oracle/components_oracle.py's metric functions against values produced by the reference's own metrics.py
     (oracle/make_golden_components.py): identical rounded percentages and branch counts."""

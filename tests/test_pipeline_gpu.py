@@ -54,6 +54,30 @@ def test_reference_fixture_stage1_batches_bit_exact(A, golden_dir):
     np.testing.assert_array_equal(out["data"].cpu().numpy(), g["s2_data"])
 
 
+def test_reference_fixture_stage2_stage3_batches_bit_exact(A, golden_dir):
+    """Seeded AirwayHMData / AirwayHMData3 batches (data.py:359-408, 546-584) produced by the reference's own crop / process_img /
+    augment methods and sampler functions: the GPU samplers take the same draws and build the same tensors, bit for bit (int16
+    crops normalised in float64, float16 weight power, label / skeleton crops, flips and axis swaps)."""
+    from scipy import ndimage
+    g = np.load(os.path.join(golden_dir, "pipeline_hm_known.npz"))
+    img, label, skeleton, pred, cube, b = g["img"], g["label"], g["skeleton"], g["pred"], int(g["cube"]), int(g["batch"])
+    dis = ndimage.distance_transform_edt(label)
+    loc_skel, loc_small, loc_break = np.where(skeleton * (1 - pred)), np.where((dis * skeleton) < 2), tuple(g["br_skel"])
+    dev = lambda a: torch.from_numpy(a).cuda()
+    ds2 = A.AirwayHMDataGPU(dev(img), dev(label), dev(g["weight16"]), loc_skel, loc_small, b, cube=cube)
+    # stage 3's weight volume = LIB + 0.6 * break weight, formed in float16 like data.py:553-557
+    ds3 = A.AirwayHMData3GPU(dev(img), dev(label), dev(g["weight3"]), dev(skeleton), loc_skel, loc_small, loc_break, b, cube=cube)
+    for seed in (1, 2):
+        for stage, ds in ((2, ds2), (3, ds3)):
+            random.seed(300 + seed)
+            np.random.seed(400 + seed)
+            out = ds.sample()
+            for k in ("data", "label", "weight") + (("skel",) if stage == 3 else ()):
+                got, want = out[k].cpu().numpy(), g[f"s{stage}_{seed}_{k}"]
+                assert got.dtype == np.float32 and got.shape == want.shape
+                np.testing.assert_array_equal(got, want, err_msg=f"stage {stage} seed {seed} {k}")
+
+
 @pytest.mark.parametrize("code", list(range(16)))
 def test_every_axis_map_against_oracle(A, po, code):
     img, label, w16, skel = _case(code, (70, 66, 100))
