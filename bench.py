@@ -395,14 +395,14 @@ def main():
                                "selection": "launch group with the largest total time in a fully marked warm-up step; timed here "
                                             "with HIP events on the launch stream inside the timed region"}
             # HBM traffic of that kernel from rocprofv3 PMC passes over THIS command (scripts/pmc_traffic.sh ->
-            # profiles/r02_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x2 per the gfx950 note
+            # profiles/r03_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x2 per the gfx950 note
             # in MI355X_MICROARCH.md)
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
             if os.path.exists(tpath) and B == 4 and S == 128 and args.dtype == "bf16" and args.width == 1:
                 t = json.load(open(tpath)).get("kernels", {}).get(tag)
                 if t:
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc over bench.py, per launch)"
+                    out["roofline"]["traffic_source"] = "profiles/r03_traffic.json (rocprofv3 --pmc over bench.py, per launch)"
 
     # ---- SURVEY 8(d)'s metric as stated: forward + loss + backward (+ the gradient all-reduce for N > 1), no optimizer
     if not args.no_secondary and not args.no_optimizer:

@@ -49,6 +49,30 @@ for key, (f, w) in table.items():
     name, items, wg = key
     if "conv_igemm_kernel" in name and is27(name) and items == 4096 * 2 * 4 * 256: groups["dgrad:dc5"] = (f, w)
     if "conv_igemm_kernel" in name and is27(name) and items == 4096 * 1 * 4 * 256: groups["conv_fwd:dc5"] = (f, w)
+# round 3: dc5 runs on the marching kernel (csrc/conv_march.hip), 256 workgroups of 256 threads at the bench shape.
+# conv_march_kernel<T, KS, NGW, RYW, DIL, MODE>: the data gradient of dc5 is the only <.., 1, 4, 8, 1, 1> launch of a step; its
+# forward <.., 2, 2, 4, 1, 0> shares instantiation and grid with dc4's forward and is the LAST such launch of every forward pass.
+def march_is(name, sig):
+    n = name.replace(" ", "")
+    return "conv_march_kernel" in n and (",".join(map(str, sig)) + ">" in n or "".join("Li%dE" % v for v in sig) in n)
+def last_of_each_step(v):
+    v = sorted(v)
+    per = max(len(v) // STEPS, 1)
+    return [x for i, x in enumerate(v) if i % per == per - 1]
+for key in fetch:
+    name, items, wg = key
+    for tag, sig, pick in (("dgrad:dc5", (1, 4, 8, 1, 1), None), ("conv_fwd:dc5", (2, 2, 4, 1, 0), last_of_each_step)):
+        if march_is(name, sig) and items == 256 * 256:
+            fv, wv = fetch[key].get("FETCH_SIZE", []), write.get(key, {}).get("WRITE_SIZE", [])
+            if pick:
+                fv, wv = pick(fv), pick(wv)
+            groups[tag] = (avg(fv) * 1024 * 2, avg(wv) * 1024)
+            c = sq.get(key, {})
+            mv, bv = c.get("SQ_VALU_MFMA_BUSY_CYCLES", []), c.get("SQ_BUSY_CU_CYCLES", [])
+            if pick:
+                mv, bv = pick(mv), pick(bv)
+            if bv:
+                print("%-90s %10s %12.3e %12.3e %10.3f   (%s)" % (key[0], "dc5", avg(mv), avg(bv), avg(mv) / avg(bv), tag))
 for key in fetch:
     name, items, wg = key
     if "wgrad_kernel" in name and "stream" not in name and ("Li27ELi1E" in name or ", 27, 1" in name) and items == 256 * 2 * 256:
