@@ -132,6 +132,8 @@ int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, c
   SEUNET_CHECK(dy && dw, "conv3d_wgrad: null tensor");
   if (impl == SEUNET_CONV_NAIVE) return launch_wgrad_naive(dtype, taps, dilation, sl, cin, dy, cout, dw, D(dims), S(s));
   SEUNET_CHECK(workspace, "conv3d_wgrad: null workspace");
+  if (impl == SEUNET_CONV_MARCH)
+    return launch_wgrad_march(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s));
   return launch_wgrad(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s));
 }
 

@@ -456,6 +456,8 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   SEUNET_CHECK(x.n >= 1 && x.n <= 3, "wgrad: 1..3 sources");
   SEUNET_CHECK(cout % 8 == 0 && cin_logical >= 1 && cin_logical <= x.total(), "wgrad: bad channel counts");
   SEUNET_CHECK(ws_bytes >= wgrad_workspace_bytes(taps, cin_logical, cout), "wgrad: workspace too small");
+  if (wgrad_march_supported(dtype, taps, dil, x, cin_logical, cout, d))     // wide layers of the fine levels: wgrad_march.hip
+    return launch_wgrad_march(dtype, taps, dil, x, cin_logical, dy, cout, dw, workspace, ws_bytes, d, s);
   WgArgs a{};
   a.src0 = x.ptr[0]; a.srcC0 = x.C[0];
   a.src1 = x.n > 1 ? x.ptr[1] : nullptr; a.srcC1 = x.n > 1 ? x.C[1] : 0;
