@@ -53,8 +53,8 @@ for name, split, cout, dil, size in CASES:
     nb = lib.seunet_conv3d_wgrad_workspace_bytes(TAPS, cin, cout)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     dw = torch.empty((cout, cin, K, K, K), device="cuda")
-    def wgrad():
-        _lib.check(lib.seunet_conv3d_wgrad(code, 0, TAPS, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, dy.data_ptr(), cout,
+    def wgrad(impl=3):
+        _lib.check(lib.seunet_conv3d_wgrad(code, impl, TAPS, dil, len(srcs), _lib.ptr_array(srcs), _lib.int_array(split), cin, dy.data_ptr(), cout,
                                            dw.data_ptr(), ws.data_ptr(), nb, dims, _lib.stream_ptr()))
     # the marching kernel (csrc/conv_march.hip) on the same operands, where it serves the shape
     march = TAPS == 27 and bool(lib.seunet_conv3d_march_supported(code, dil, len(srcs), _lib.int_array(split), 1, _lib.int_array([cout])))
@@ -113,4 +113,9 @@ for name, split, cout, dil, size in CASES:
         err = max(float((a.float() - b.float()).abs().max()) / float(b.float().abs().max()) for a, b in zip(gs_m, gs))
         ms = timeit(mdgrad)
         res.append("MARCH dgrad %.3f ms %.0f TF/s (rel diff %.1e)" % (ms, flops / ms / 1e9, err))
+    if TAPS == 27 and cin % 32 == 0 and cout % 32 == 0 and len(set(split)) == 1 and len(split) <= 2 and "wgrad" in which:
+        wgrad(3); ref_dw = dw.clone(); wgrad(2); torch.cuda.synchronize()
+        err = float((dw - ref_dw).abs().max()) / float(ref_dw.abs().max())
+        ms = timeit(lambda: wgrad(2))
+        res.append("MARCH wgrad %.3f ms %.0f TF/s (rel diff %.1e)" % (ms, flops / ms / 1e9, err))
     print("%-4s %s->%d d%d @%d^3 B%d: " % (name, split, cout, dil, size, B) + " | ".join(res), flush=True)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEUNET_LIB") or os.path.join(_HERE, "libseunet_hip.so")   # SEUNET_LIB: diagnostic builds only
 
 F32, BF16, F16 = 0, 1, 2
-CONV_MFMA, CONV_NAIVE, CONV_MARCH = 0, 1, 2
+CONV_MFMA, CONV_NAIVE, CONV_MARCH, CONV_TILED = 0, 1, 2, 3
 LOSS_NSUMS = 7
 DTI_F64, DTI_F32 = 0, 1
 CC_EVALUATION, CC_MAXIMUM_3D = 0, 1

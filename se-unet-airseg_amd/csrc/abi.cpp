@@ -134,7 +134,7 @@ int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, c
   SEUNET_CHECK(workspace, "conv3d_wgrad: null workspace");
   if (impl == SEUNET_CONV_MARCH)
     return launch_wgrad_march(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s));
-  return launch_wgrad(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s));
+  return launch_wgrad(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s), impl != SEUNET_CONV_TILED);
 }
 
 int seunet_epilogue_slots(seunet_dims dims) { return epi_partials(D(dims)); }

@@ -254,7 +254,7 @@ int launch_wgrad_stream(int dtype, int dil, const void* x, int x_c, int cin_w, c
 size_t wgrad_workspace_bytes(int taps, int cin, int cout);
 int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy,
                  int cout, float* dw_torch, void* workspace, size_t ws_bytes, Dims d,
-                 hipStream_t s);
+                 hipStream_t s, bool allow_march = true);
 // marching weight gradient (wgrad_march.hip); `supported` includes the size gate launch_wgrad dispatches on
 bool wgrad_march_supported(int dtype, int taps, int dil, const SrcList& x, int cin_logical, int cout, Dims d);
 int launch_wgrad_march(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy, int cout,

@@ -450,13 +450,13 @@ static int wgrad_launch_one(const WgArgs& a, dim3 grid, hipStream_t s) {
 // x: input activation (may be a concatenation), cin_logical leading channels carry weights;
 // dy: gradient w.r.t. the raw conv output, [N][V][cout]; dw: (cout, cin_logical, taps) f32, overwritten.
 int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy, int cout,
-                 float* dw, void* workspace, size_t ws_bytes, Dims d, hipStream_t s) {
+                 float* dw, void* workspace, size_t ws_bytes, Dims d, hipStream_t s, bool allow_march) {
   SEUNET_CHECK(taps == 27 || taps == 1, "wgrad: taps=%d unsupported", taps);
   SEUNET_CHECK(taps == 1 || dil == 1 || dil == 2, "wgrad: dilation %d unsupported", dil);
   SEUNET_CHECK(x.n >= 1 && x.n <= 3, "wgrad: 1..3 sources");
   SEUNET_CHECK(cout % 8 == 0 && cin_logical >= 1 && cin_logical <= x.total(), "wgrad: bad channel counts");
   SEUNET_CHECK(ws_bytes >= wgrad_workspace_bytes(taps, cin_logical, cout), "wgrad: workspace too small");
-  if (wgrad_march_supported(dtype, taps, dil, x, cin_logical, cout, d))     // wide layers of the fine levels: wgrad_march.hip
+  if (allow_march && wgrad_march_supported(dtype, taps, dil, x, cin_logical, cout, d))     // wide layers of the fine levels: wgrad_march.hip
     return launch_wgrad_march(dtype, taps, dil, x, cin_logical, dy, cout, dw, workspace, ws_bytes, d, s);
   WgArgs a{};
   a.src0 = x.ptr[0]; a.srcC0 = x.C[0];

@@ -82,11 +82,14 @@ template <int N, typename F> __device__ __forceinline__ void wm_for(F&& f) {
   }(std::make_integer_sequence<int, N>{});
 }
 
-template <typename T> __device__ __forceinline__ wmf32x4 wm_mfma(wmb16x8 a, wmb16x8 b, wmf32x4 c) {
-  if constexpr (std::is_same<T, f16_t>::value)
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wmf16x8, a), __builtin_bit_cast(wmf16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+// The matrix instruction as inline asm with the accumulator pinned to the accumulator half of the register file ("+a": D = C
+// in place).  Through the builtin the register allocator spread the 216 accumulator registers over both halves and then
+// spilled fragments; the asm leaves the vector half to the fragments and addresses.  Its operands are ordinary data
+// dependencies (the compiler still waits for the LDS reads that produce them); an accumulator is only read back after the
+// last march (behind explicit wait states).
+template <typename T> __device__ __forceinline__ void wm_mfma(wmf32x4& c, wmb16x8 a, wmb16x8 b) {
+  if constexpr (std::is_same<T, f16_t>::value) asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
 // 8 voxels of one channel: two transposing reads of 4 voxels x 16 channels each (lane i of a 16-lane group receives channel i)
@@ -101,6 +104,23 @@ __device__ __forceinline__ wmb16x8 wm_frag(unsigned addr0, unsigned addr1) {
 template <int DIL, int HY> __host__ __device__ constexpr int wm_row(int i) {
   if constexpr (DIL == 1) return i;
   else return i < (HY + 1) / 2 ? 2 * i : 2 * (i - (HY + 1) / 2) + 1;
+}
+
+// the v-th y-tap (oldest dY row first: ty = 2, 1, 0) that pairs X row hy with a dY row inside the patch
+template <int DIL> __host__ __device__ constexpr int wm_tap_y(int hy, int v) {
+  for (int ty = 2; ty >= 0; --ty) {
+    const int r = hy - DIL * ty;
+    if (r >= 0 && r < WM_RY) { if (v == 0) return ty; --v; }
+  }
+  return -1;
+}
+template <int DIL, int HY, int PW> __host__ __device__ constexpr int wm_row_mfmas(int i) {
+  int n = 0;
+  for (int ty = 0; ty < 3; ++ty) { const int r = wm_row<DIL, HY>(i) - DIL * ty; n += (r >= 0 && r < WM_RY) ? 9 * PW : 0; }
+  return n;
+}
+template <int DIL, int HY, int PW> __host__ __device__ constexpr int wm_row_frags(int i) {
+  return 3 + (wm_row<DIL, HY>(i) < WM_RY ? 3 * PW : 0);
 }
 
 template <typename T, int NCB, int NOB, int DIL>
@@ -191,50 +211,34 @@ wgrad_march_kernel(WmArgs a) {
     const unsigned char* x1_n = reinterpret_cast<const unsigned char*>(a.nsrc > 1 ? a.src1 : a.src0) + (long long)n * a.D * xplane;
     const unsigned char* dy_n = reinterpret_cast<const unsigned char*>(a.dy) + (long long)n * a.D * yplane;
 
-    // X plane of step s -> slot xs, dY plane s -> slot ys; every wave issues exactly TOT instructions
-    auto issue = [&](int s, int xs, int ys) __attribute__((always_inline)) {
-      {
+    // DMA instruction `it` of the planes of step s (X plane -> slot xs, dY plane s -> slot ys); every wave issues exactly TOT
+    // instructions per step (padding instructions land in the dump area)
+    auto issue_item = [&](int s, int xs, int ys, auto it_c) __attribute__((always_inline)) {
+      constexpr int it = decltype(it_c)::value;
+      if constexpr (it < ITEMSX) {
         const int pl = q0 - 1 + s;
         const int z = pz + DIL * pl;
         const bool zok = pl >= 0 && z < a.D && s < nsteps;            // wave-uniform
         const long long zb = (long long)(zok ? z : 0) * xplane;
-#pragma unroll
-        for (int it = 0; it < ITEMSX; ++it) {
-          const bool real = wave + WM_NW * it < NIX;                  // wave-uniform
-          const unsigned d = dox[it];
-          const unsigned char* gp = ((d & 0x80000000u) ? x1_n : x0_n) + zb + (d & 0x7FFFFFFFu);
-          gp = (zok && d != 0xFFFFFFFFu) ? gp : zero_page;
-          wm_dma16(gp, real ? lds_base + (unsigned)(xs * PLBX + (wave + WM_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
-        }
-      }
-      {
+        const bool real = wave + WM_NW * it < NIX;                    // wave-uniform
+        const unsigned d = dox[it];
+        const unsigned char* gp = ((d & 0x80000000u) ? x1_n : x0_n) + zb + (d & 0x7FFFFFFFu);
+        gp = (zok && d != 0xFFFFFFFFu) ? gp : zero_page;
+        wm_dma16(gp, real ? lds_base + (unsigned)(xs * PLBX + (wave + WM_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
+      } else {
+        constexpr int iy = it - ITEMSX;
         const bool zok = s < Z;                                       // wave-uniform
         const long long zb = (long long)(zok ? pz + DIL * (q0 + s) : 0) * yplane;
-#pragma unroll
-        for (int it = 0; it < ITEMSY; ++it) {
-          const unsigned d = doy[it];
-          const unsigned char* gp = (zok && d != 0xFFFFFFFFu) ? dy_n + zb + d : zero_page;
-          wm_dma16(gp, zok ? lds_base + (unsigned)(Geo::YOFF + ys * PLBY + (wave + WM_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
-        }
+        const unsigned d = doy[iy];
+        const unsigned char* gp = (zok && d != 0xFFFFFFFFu) ? dy_n + zb + d : zero_page;
+        wm_dma16(gp, zok ? lds_base + (unsigned)(Geo::YOFF + ys * PLBY + (wave + WM_NW * iy) * 1024) : lds_base + (unsigned)Geo::DUMP);
       }
     };
 
-    wm_wait_vm<0>();
-    __syncthreads();                     // the previous item's readers are done; the zero plane is written
-    if (nsteps == 0) continue;           // (block-uniform)
-    issue(0, 0, 0);
-    issue(1, 1, 1);
-    int xs = 0, ys = 0;                  // ring slots of step s: s % 3, s % 5
-    for (int s = 0; s < nsteps; ++s) {
-      wm_wait_vm<TOT>();
-      __builtin_amdgcn_s_barrier();
-      {
-        const int xs2 = xs + 2 >= WM_XRING ? xs + 2 - WM_XRING : xs + 2;
-        const int ys2 = ys + 2 >= WM_YRING ? ys + 2 - WM_YRING : ys + 2;
-        issue(s + 2, xs2, ys2);
-      }
-      // dY plane bases of dz = 0, 1, 2: planes s, s-1, s-2 (a plane outside the march reads the zero plane)
-      unsigned xa[3][2], ya[3][PW][2];
+    // fragment addresses of a step: X plane in slot xs; dY planes s, s-1, s-2 (dz = 0, 1, 2) in slots ys, ys-1, ys-2 -- a plane
+    // outside the march reads the zero plane
+    unsigned xa[3][2], ya[3][PW][2];
+    auto set_addr = [&](int s, int xs, int ys) __attribute__((always_inline)) {
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -249,46 +253,84 @@ wgrad_march_kernel(WmArgs a) {
 #pragma unroll
           for (int r = 0; r < 2; ++r) ya[tz][k][r] = pb + yoff[k][r];
       }
-      wmb16x8 xf[2][3];
-      wmb16x8 yw[RY][3][PW];
-      auto load_row = [&](auto i_c) __attribute__((always_inline)) {
+    };
+    wmb16x8 xf[2][3];
+    wmb16x8 yw[RY][3][PW];
+    // fragment f of row i (processing order) of the current addresses: f < 3: X, x-tap f; else dY row hy of plane tz, pair k
+    auto load_frag = [&](auto i_c, auto f_c) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value, f = decltype(f_c)::value;
+      constexpr int hy = wm_row<DIL, HY>(i);
+      if constexpr (f < 3) xf[i & 1][f] = wm_frag(xa[f][0] + hy * ROWBX, xa[f][1] + hy * ROWBX);
+      else {
+        constexpr int tz = (f - 3) / PW, k = (f - 3) % PW;
+        yw[hy][tz][k] = wm_frag(ya[tz][k][0] + hy * ROWBY, ya[tz][k][1] + hy * ROWBY);
+      }
+    };
+    // MFMA m of row i: (the m / 9PW-th valid y-tap, oldest dY row first; dz; x-tap; pair)
+    auto mfma_one = [&](auto i_c, auto m_c) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value, m = decltype(m_c)::value;
+      constexpr int hy = wm_row<DIL, HY>(i);
+      constexpr int ty = wm_tap_y<DIL>(hy, m / (9 * PW));
+      constexpr int rem = m % (9 * PW), tz = rem / (3 * PW), dx = (rem / PW) % 3, k = rem % PW;
+      constexpr int r = hy - DIL * ty;
+      static_assert(r >= 0 && r < RY, "row pairing");
+      wm_mfma<T>(acc[k][(tz * 3 + ty) * 3 + dx], yw[r][tz][k], xf[i & 1][dx]);
+    };
+    // one row: the fragments of row `nx` are requested one by one between equal shares of row i's MFMAs (hand-placed:
+    // sched_barrier fences keep the order), so that every read has most of a row of MFMAs to land
+    auto row = [&](auto i_c, auto nx_c, auto&& extra) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value, nx = decltype(nx_c)::value;
+      constexpr int NF = wm_row_frags<DIL, HY, PW>(nx), NM = wm_row_mfmas<DIL, HY, PW>(i);
+      extra();
+      wm_for<NF>([&](auto g_c) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_c)::value;
+        load_frag(nx_c, g_c);
+        wm_for<(g + 1) * NM / NF - g * NM / NF>([&](auto j_c) __attribute__((always_inline)) {
+          mfma_one(i_c, std::integral_constant<int, g * NM / NF + decltype(j_c)::value>{});
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    // Vector-memory operations of a wave, in program order: [prologue: planes 0 and 1], then per step s exactly TOT: the planes
+    // of step s + 2 (issued during the rows of step s).  The step ends with the synchronisation FOR THE NEXT STEP, placed
+    // before the MFMAs of its last row: all LDS reads of the step are done (lgkmcnt(0)), at most the TOT instructions of this
+    // step are outstanding (planes s + 1 have landed), one barrier (every wave's part is in, every wave is done reading the
+    // slots of step s -- which the DMA of step s + 1 overwrites); then the first row of step s + 1 is requested and the last
+    // row's MFMAs cover its latency.
+    wm_wait_vm<0>();
+    __syncthreads();                     // the previous item's readers are done; the zero plane is written
+    if (nsteps == 0) continue;           // (block-uniform)
+    wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) { issue_item(0, 0, 0, it_c); });
+    wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) { issue_item(1, 1, 1, it_c); });
+    wm_wait_vm<TOT>();
+    __builtin_amdgcn_s_barrier();
+    int xs = 0, ys = 0;                  // ring slots of step s: s % 3, s % 5
+    set_addr(0, 0, 0);
+    wm_for<wm_row_frags<DIL, HY, PW>(0)>([&](auto f_c) __attribute__((always_inline)) { load_frag(std::integral_constant<int, 0>{}, f_c); });
+    for (int s = 0; s < nsteps; ++s) {
+      const int xs2 = xs + 2 >= WM_XRING ? xs + 2 - WM_XRING : xs + 2;
+      const int ys2 = ys + 2 >= WM_YRING ? ys + 2 - WM_YRING : ys + 2;
+      wm_for<HY - 1>([&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
-        if constexpr (i < HY) {
-          constexpr int hy = wm_row<DIL, HY>(i);
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) xf[i & 1][dx] = wm_frag(xa[dx][0] + hy * ROWBX, xa[dx][1] + hy * ROWBX);
-          if constexpr (hy < RY) {
-#pragma unroll
-            for (int tz = 0; tz < 3; ++tz)
-#pragma unroll
-              for (int k = 0; k < PW; ++k) yw[hy][tz][k] = wm_frag(ya[tz][k][0] + hy * ROWBY, ya[tz][k][1] + hy * ROWBY);
-          }
-        }
-      };
-      load_row(std::integral_constant<int, 0>{});
-      wm_for<HY>([&](auto i_c) __attribute__((always_inline)) {
-        constexpr int i = decltype(i_c)::value;
-        constexpr int hy = wm_row<DIL, HY>(i);
-        load_row(std::integral_constant<int, i + 1>{});
-        // oldest dY row first (its registers are the next to be reused)
-        wm_for<3>([&](auto t_c) __attribute__((always_inline)) {
-          constexpr int ty = 2 - decltype(t_c)::value;
-          constexpr int r = hy - DIL * ty;
-          if constexpr (r >= 0 && r < RY) {
-#pragma unroll
-            for (int tz = 0; tz < 3; ++tz)
-#pragma unroll
-              for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int k = 0; k < PW; ++k)
-                  acc[k][(tz * 3 + ty) * 3 + dx] = wm_mfma<T>(yw[r][tz][k], xf[i & 1][dx], acc[k][(tz * 3 + ty) * 3 + dx]);
-          }
+        row(i_c, std::integral_constant<int, i + 1>{}, [&]() __attribute__((always_inline)) {
+          wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) {
+            constexpr int it = decltype(it_c)::value;
+            if constexpr ((it * (HY - 1)) / TOT == i) issue_item(s + 2, xs2, ys2, it_c);
+          });
         });
       });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wm_wait_vm<TOT>();
+      __builtin_amdgcn_s_barrier();
       xs = xs + 1 == WM_XRING ? 0 : xs + 1;
       ys = ys + 1 == WM_YRING ? 0 : ys + 1;
+      set_addr(s + 1, xs, ys);
+      row(std::integral_constant<int, HY - 1>{}, std::integral_constant<int, 0>{}, []() {});
     }
   }
+  // (wait states between the last MFMA and the reads of its result below)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   wm_wait_vm<0>();
 
   // ---- slab of this workgroup: [pair = wave * PW + k][tap][lane][4] ----
