@@ -195,6 +195,11 @@ int seunet_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
 int seunet_loss_partial_floats(void);
 int seunet_loss_sums(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
                      long long n, float* partial, double* sums, int terms, seunet_stream_t s);
+/* loss value of one head (sums1 == NULL) or of a training stage's two heads from their sums, on the device:
+ * f32(c_dice*dice + c_gul*gul + c_atr*atr of sums0) + f32(the same of sums1), each formed in f64 (the scalar arithmetic of
+ * train.py:51-76 and the stage sums train.py:597-599,433-435,241-243 without a dozen one-element kernels). */
+int seunet_loss_value(const double* sums0, double c_dice0, double c_gul0, double c_atr0, const double* sums1, double c_dice1,
+                      double c_gul1, double c_atr1, float* value, seunet_stream_t s);
 int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
                      long long n, const double* sums, float c_dice, float c_gul, float c_atr, float g_scale,
                      const float* g_scale_dev, float* g_pred, seunet_stream_t s);

@@ -30,7 +30,7 @@ class NetDesc(C.Structure):
                 ("negative_slope", C.c_float), ("eps", C.c_float)]
 
 
-_vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+_vp, _i, _f, _ll, _sz, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t, C.c_double
 _pp = C.POINTER(C.c_void_p)
 _ip = C.POINTER(C.c_int)
 
@@ -78,6 +78,7 @@ PROTOTYPES = {
     "seunet_head_bwd": (_i, [_vp, _pp, _i, _vp, _vp, Dims, _vp]),
     "seunet_loss_partial_floats": (_i, []),
     "seunet_loss_sums": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _vp, _vp, _i, _vp]),
+    "seunet_loss_value": (_i, [_vp, _d, _d, _d, _vp, _d, _d, _d, _vp, _vp]),
     "seunet_loss_grad": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     "seunet_cat_xgrad_records": (_i, [Dims]),
     "seunet_xbranch_moment_slots": (_i, [Dims]),

@@ -232,6 +232,11 @@ int seunet_loss_sums(const float* pred, int apply_sigmoid, const float* target, 
   SEUNET_CHECK(terms >= 0 && terms <= 7, "loss_sums: terms=%d is not a mask of SEUNET_LOSS_DICE | _GUL | _ATR", terms);
   return launch_loss_sums(pred, apply_sigmoid, target, weight, skel, n, partial, sums, S(s), terms);
 }
+int seunet_loss_value(const double* sums0, double c_dice0, double c_gul0, double c_atr0, const double* sums1, double c_dice1,
+                      double c_gul1, double c_atr1, float* value, seunet_stream_t s) {
+  SEUNET_CHECK(sums0 && value, "loss_value: null argument");
+  return launch_loss_value(sums0, c_dice0, c_gul0, c_atr0, sums1, c_dice1, c_gul1, c_atr1, value, S(s));
+}
 int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, const float* weight, const float* skel,
                      long long n, const double* sums, float c_dice, float c_gul, float c_atr, float g_scale,
                      const float* g_scale_dev, float* g_pred, seunet_stream_t s) {

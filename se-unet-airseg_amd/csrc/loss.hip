@@ -145,6 +145,31 @@ int launch_loss_sums(const float* pred, int apply_sigmoid, const float* target, 
   return 0;
 }
 
+// loss value from the (already all-reduced) sums of one or two heads, formed on the device in f64 and rounded to f32 per
+// head like the reference's scalar arithmetic (train.py:51-76 on whole-batch sums): value = f32(head 0) + f32(head 1)
+__global__ void loss_value_kernel(const double* __restrict__ s0, double d0, double g0, double a0,
+                                  const double* __restrict__ s1, double d1, double g1, double a1, float* __restrict__ value) {
+  auto one = [](const double* s, double cd, double cg, double ca) -> float {
+    double out = 0.0;
+    if (cd != 0.0) out = out + cd * (1.0 - (2.0 * s[0] + 1.0) / (s[1] + s[2] + 1.0));
+    if (cg != 0.0) out = out + cg * (1.0 - (s[3] + 1.0) / (s[4] + 1.0));
+    if (ca != 0.0) out = out + ca * (1.0 - (s[5] + 1.0) / (s[6] + 1.0));
+    return (float)out;
+  };
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float v = one(s0, d0, g0, a0);
+    if (s1 != nullptr) v = v + one(s1, d1, g1, a1);
+    value[0] = v;
+  }
+}
+
+int launch_loss_value(const double* sums0, double c_dice0, double c_gul0, double c_atr0, const double* sums1, double c_dice1,
+                      double c_gul1, double c_atr1, float* value, hipStream_t s) {
+  loss_value_kernel<<<1, 64, 0, s>>>(sums0, c_dice0, c_gul0, c_atr0, sums1, c_dice1, c_gul1, c_atr1, value);
+  SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_loss_grad(const float* pred, int apply_sigmoid, const float* target, const float* weight,
                      const float* skel, long long n, const double* sums, float c_dice, float c_gul,
                      float c_atr, float g_scale, const float* g_scale_dev, float* g_pred, hipStream_t s) {

@@ -809,6 +809,89 @@ head_fwd_kernel(HeadLevels lv, const float* __restrict__ bias, float* __restrict
     *reinterpret_cast<float4*>(pred + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
+// Row form of the same head: a block per (n, z) plane, ONE WAVE per output row.  The per-voxel form above issues 8 four-byte
+// gathers per level and output and decodes its 64-bit flat index per thread (~400 vector instructions per 4 voxels: 62 us per
+// head at 4 x 128^3 against 12 us of HBM time).  Here everything that depends on (n, z, y) only is wave-uniform (scalar
+// registers); the lanes first blend the four (z, y) source rows of a level with coalesced loads -- c[xc] = w00 r00[xc] + w01
+// r01[xc] + w10 r10[xc] + w11 r11[xc], W >> l values -- into a per-wave LDS row, then every lane interpolates its outputs along
+// x from that row with x indices / weights tabulated once per thread.  Same products and association as head_fwd_kernel.
+constexpr int HF_RPW = 4;     // rows per wave: their loads are issued together (a wave that walks its rows one by one is a
+                              // chain of dependent global load -> LDS -> read -> store latencies)
+__global__ void __launch_bounds__(256)
+head_fwd_rows_kernel(HeadLevels lv, const float* __restrict__ bias, float* __restrict__ pred, int D, int H, int W) {
+  extern __shared__ float hrow[];                       // [4 waves][HF_RPW rows][W/2 + W/4 + W/8]
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int per_row = (W >> 1) + (W >> 2) + (W >> 3);
+  float* const rb = hrow + wv * HF_RPW * per_row;
+  const float b0 = bias[0];
+  const int ybl = (H + 4 * HF_RPW - 1) / (4 * HF_RPW);           // y blocks per plane
+  const int yb = blockIdx.x % ybl, zo = (blockIdx.x / ybl) % D, n = blockIdx.x / (ybl * D);
+  const int ybase = (yb * 4 + wv) * HF_RPW;
+  // the level-0 values of the first pass over x (requested first: they arrive while the coarse rows are blended)
+  float2 v0[HF_RPW];
+#pragma unroll
+  for (int r = 0; r < HF_RPW; ++r) {
+    const int yo = ybase + r < H ? ybase + r : H - 1;
+    v0[r] = (lv.map[0] && 2 * lane < W) ? *reinterpret_cast<const float2*>(lv.map[0] + (((long long)n * D + zo) * H + yo) * W + 2 * lane)
+                                        : make_float2(0.f, 0.f);
+  }
+  // x tables of this lane's first two outputs (x = 2 lane, 2 lane + 1); further passes (W > 128) recompute
+  int tx0[3][2], tx1[3][2]; float tlx[3][2];
+#pragma unroll
+  for (int l = 1; l < 4; ++l)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) ac_src(2 * lane + k, ac_scale(W >> l, W), W >> l, tx0[l - 1][k], tx1[l - 1][k], tlx[l - 1][k]);
+#pragma unroll
+  for (int l = 1; l < 4; ++l) {
+    if (!lv.map[l]) continue;
+    const int Dl = D >> l, Hl = H >> l, Wl = W >> l;
+    int z0, z1; float lz;
+    ac_src(zo, ac_scale(Dl, D), Dl, z0, z1, lz);
+    const float* m = lv.map[l] + (long long)n * Dl * Hl * Wl;
+    const int lbase = (l > 1 ? (W >> 1) : 0) + (l > 2 ? (W >> 2) : 0);
+#pragma unroll
+    for (int r = 0; r < HF_RPW; ++r) {
+      const int yo = ybase + r < H ? ybase + r : H - 1;
+      int y0, y1; float ly;
+      ac_src(yo, ac_scale(Hl, H), Hl, y0, y1, ly);
+      const float* r00 = m + (z0 * Hl + y0) * Wl;
+      const float* r01 = m + (z0 * Hl + y1) * Wl;
+      const float* r10 = m + (z1 * Hl + y0) * Wl;
+      const float* r11 = m + (z1 * Hl + y1) * Wl;
+      const float w00 = (1.f - lz) * (1.f - ly), w01 = (1.f - lz) * ly, w10 = lz * (1.f - ly), w11 = lz * ly;
+      for (int xc = lane; xc < Wl; xc += 64)
+        rb[r * per_row + lbase + xc] = w00 * r00[xc] + w01 * r01[xc] + w10 * r10[xc] + w11 * r11[xc];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                      // LDS operations of one wave complete in order
+#pragma unroll
+  for (int r = 0; r < HF_RPW; ++r) {
+    const int yo = ybase + r;
+    if (yo >= H) break;                                 // (wave-uniform)
+    const long long orow = (((long long)n * D + zo) * H + yo) * W;
+    for (int x = 2 * lane; x < W; x += 128) {
+      float acc[2] = {b0, b0};
+      if (lv.map[0]) {
+        const float2 v = x < 128 ? v0[r] : *reinterpret_cast<const float2*>(lv.map[0] + orow + x);
+        acc[0] += v.x; acc[1] += v.y;
+      }
+      int lb = r * per_row;
+#pragma unroll
+      for (int l = 1; l < 4; ++l) {
+        if (!lv.map[l]) continue;
+        const int Wl = W >> l;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          int x0 = tx0[l - 1][k], x1 = tx1[l - 1][k]; float lx = tlx[l - 1][k];
+          if (x >= 128) ac_src(x + k, ac_scale(Wl, W), Wl, x0, x1, lx);
+          acc[k] += (1.f - lx) * rb[lb + x0] + lx * rb[lb + x1];
+        }
+        lb += Wl;
+      }
+      *reinterpret_cast<float2*>(pred + orow + x) = make_float2(acc[0], acc[1]);
+    }
+  }
+}
 // transposed 1-D interpolation along one axis of an f32 tensor viewed as [outer][O][inner] -> [outer][I][inner]
 __global__ void up_transpose_axis_kernel(const float* __restrict__ in, float* __restrict__ out, int I, int O,
                                          long long inner, long long total) {
@@ -867,11 +950,35 @@ head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, fl
   __syncthreads();
   double sum = 0.0;
   const long long row0 = (long long)blockIdx.x * HB_ROWS;
+  // rows of up to 256 values: the next row of this wave is fetched (registers) before the current one is processed -- the
+  // loop is otherwise a chain of dependent global load -> LDS -> compute per row
+  const bool pf = W <= 256;
+  float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](long long row) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x = lane + 64 * k;
+      nxt[k] = (row < rows && x < W) ? g[row * W + x] : 0.f;
+    }
+  };
+  if (pf) fetch(row0 + wv);
   for (int rr = wv; rr < HB_ROWS; rr += 4) {
     const long long row = row0 + rr;
     if (row >= rows) break;                              // (wave-uniform)
     float* rb = hsm + wv * W;
-    for (int x = lane; x < W; x += 64) { const float v = g[row * W + x]; rb[x] = v; sum += (double)v; }
+    if (pf) {
+      float cur[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+      if (rr + 4 < HB_ROWS) fetch(row + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = lane + 64 * k;
+        if (x < W) { rb[x] = cur[k]; sum += (double)cur[k]; }
+      }
+    } else {
+      for (int x = lane; x < W; x += 64) { const float v = g[row * W + x]; rb[x] = v; sum += (double)v; }
+    }
     __builtin_amdgcn_wave_barrier();                     // LDS operations of one wave complete in order
     for (int e = lane; e < nent; e += 64) {
       const int l = e < ebase[2] ? 1 : (e < ebase[3] ? 2 : 3);
@@ -880,9 +987,17 @@ head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, fl
       const float* t = tab + e * (HB_K + 2);
       const int first = __float_as_int(t[0]), cnt = __float_as_int(t[1]);
       float acc = 0.f;
-      for (int k = 0; k < cnt; ++k) {
-        const float w = t[2 + k];
-        if (w != 0.f) acc += w * rb[first + k];
+      for (int k = 0; k < cnt; k += 4) {                 // four taps at a time: independent LDS reads, same order of summation
+        float w[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = k + j < cnt;
+          w[j] = in ? t[2 + k + j] : 0.f;
+          v[j] = in ? rb[first + k + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (w[j] != 0.f) acc += w[j] * v[j];
       }
       out[row * (W >> l) + (e - ebase[l])] = acc;
     }
@@ -1099,8 +1214,14 @@ int launch_head_fwd(const float* const* level_maps, int nlevels, const float* bi
   for (int l = 1; l < nlevels; ++l)
     SEUNET_CHECK((d0.D >> l) >= 1 && (d0.H >> l) >= 1 && (d0.W >> l) >= 1, "head: volume too small for level %d", l);
   SEUNET_CHECK(d0.W % 4 == 0, "head: W=%d must be a multiple of 4", d0.W);
-  const long long total4 = (long long)d0.N * d0.vox() / 4;
-  head_fwd_kernel<<<grid_for(total4), 256, 0, s>>>(lv, bias, pred, d0.D, d0.H, d0.W, total4);
+  if (d0.W % 8 == 0 && d0.W <= 2048 && (long long)d0.D * d0.H * d0.W < (1ll << 31)) {   // row form: whole level rows, LDS rows fit, 32-bit in-sample offsets
+    const size_t lds = (size_t)4 * HF_RPW * ((d0.W >> 1) + (d0.W >> 2) + (d0.W >> 3)) * sizeof(float);
+    const int ybl = (d0.H + 4 * HF_RPW - 1) / (4 * HF_RPW);
+    head_fwd_rows_kernel<<<d0.N * d0.D * ybl, 256, lds, s>>>(lv, bias, pred, d0.D, d0.H, d0.W);
+  } else {
+    const long long total4 = (long long)d0.N * d0.vox() / 4;
+    head_fwd_kernel<<<grid_for(total4), 256, 0, s>>>(lv, bias, pred, d0.D, d0.H, d0.W, total4);
+  }
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -1112,17 +1233,28 @@ __global__ void __launch_bounds__(256) up_transpose_axis_multi_kernel(AxisJobs j
   const AxisJob jb = jobs.j[blockIdx.y];
   if (jb.total == 0) return;
   const float rs = ac_scale(jb.I, jb.O);
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < jb.total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const long long in_i = idx % jb.inner;
-    const int i = (int)((idx / jb.inner) % jb.I);
-    const long long outer = idx / (jb.inner * jb.I);
+  // (32-bit index arithmetic: a 64-bit division costs ~100 vector instructions and this loop has three per output; the launcher
+  // checks that every flat index of the job fits)
+  const unsigned inner = (unsigned)jb.inner, I = (unsigned)jb.I, total = (unsigned)jb.total;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const unsigned q = idx / inner;
+    const unsigned in_i = idx - q * inner;
+    const unsigned outer = q / I;
+    const int i = (int)(q - outer * I);
     int lo, hi;
     ac_range(i, rs, jb.O, lo, hi);
     float acc = 0.f;
-    for (int o = lo; o <= hi; ++o) {
-      const float w = ac_weight(o, i, rs, jb.I);
-      if (w != 0.f) acc += w * jb.in[(outer * jb.O + o) * jb.inner + in_i];
+    // four taps at a time: their loads are independent and go out together (same taps, same order of summation)
+    for (int o = lo; o <= hi; o += 4) {
+      float w[4], v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        w[k] = o + k <= hi ? ac_weight(o + k, i, rs, jb.I) : 0.f;
+        v[k] = w[k] != 0.f ? jb.in[(outer * (unsigned)jb.O + (unsigned)(o + k)) * inner + in_i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (w[k] != 0.f) acc += w[k] * v[k];
     }
     jb.out[idx] = acc;
   }
@@ -1154,6 +1286,7 @@ int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
   double* part = reinterpret_cast<double*>(tmp + ((V + V / 2 + 64 + 1) & ~1ll));
   const int nblk = (int)((rows + HB_ROWS - 1) / HB_ROWS);
   SEUNET_CHECK(d0.W <= 1024, "head_bwd: W=%d too large", d0.W);
+  SEUNET_CHECK(V / 2 < (1ll << 31), "head_bwd: %lld voxels per call exceed the 32-bit index range of the axis passes", V);
   const size_t lds = ((size_t)4 * d0.W + (size_t)(d0.W - (d0.W >> 3)) * (HB_K + 2)) * sizeof(float);
   head_bwd_x_multi_kernel<<<nblk, 256, lds, s>>>(g_pred, t1[1], t1[2], t1[3], nlevels, d0.W, rows, g_bias ? part : nullptr);
   // y-pass of every level in one launch, then z-pass of every level in one launch

@@ -378,6 +378,8 @@ int loss_partials();
 int launch_loss_sums(const float* pred, int apply_sigmoid, const float* target,
                      const float* weight, const float* skel, long long n, float* partial,
                      double* sums, hipStream_t s, int terms = 7);
+int launch_loss_value(const double* sums0, double c_dice0, double c_gul0, double c_atr0, const double* sums1, double c_dice1,
+                      double c_gul1, double c_atr1, float* value, hipStream_t s);
 int launch_loss_grad(const float* pred, int apply_sigmoid, const float* target,
                      const float* weight, const float* skel, long long n, const double* sums,
                      float c_dice, float c_gul, float c_atr, float g_scale,

@@ -366,19 +366,22 @@ def test_maxpool_tie_goes_to_first(S):
     assert torch.equal(S.from_cl(gi).cpu(), xr.grad)
 
 
-def test_heads_forward_backward(S):
-    n, d, h, w = 2, 16, 8, 24
-    maps = [gen(n, d >> l, h >> l, w >> l, seed=33 + l).requires_grad_(True) for l in range(4)]
+@pytest.mark.parametrize("case", [(2, 16, 8, 24, 4), (1, 8, 8, 136, 4), (1, 8, 4, 20, 3), (2, 8, 16, 320, 3)])
+def test_heads_forward_backward(S, case):
+    """row form (W % 8 == 0; 136: more than one pass of a wave over the row), the per-voxel form (W = 20) and the x pass of
+    the backward without its row prefetch (W = 320), against F.interpolate(align_corners=True) and autograd."""
+    n, d, h, w, nl = case
+    maps = [gen(n, d >> l, h >> l, w >> l, seed=33 + l).requires_grad_(True) for l in range(nl)]
     bias = gen(1, seed=40)
     ref = bias.view(1, 1, 1, 1, 1) + maps[0].unsqueeze(1)
-    for l in range(1, 4):
+    for l in range(1, nl):
         ref = ref + F.interpolate(maps[l].unsqueeze(1), scale_factor=2 ** l, mode="trilinear", align_corners=True)
     g = gen(*ref.shape, seed=41)
     ref.backward(g)
     pred = S.head_fwd([m.detach().cuda() for m in maps], bias.cuda())
     assert_close(pred, ref, "fp32", "head fwd")
-    levels, gb = S.head_bwd(g.cuda(), 4)
-    for l in range(1, 4):
+    levels, gb = S.head_bwd(g.cuda(), nl)
+    for l in range(1, nl):
         assert_close(levels[l], maps[l].grad, "fp32", f"head bwd level {l}")
     assert abs(float(gb.cpu()) - float(g.sum())) < 1e-3
 
@@ -407,6 +410,12 @@ def test_losses_match_oracle(S):
         (3.0 * l).backward()
         assert abs(float(l) - float(l_ref)) < 2e-6, name
         np.testing.assert_allclose(pg.grad.cpu().numpy() / 3.0, p.grad.numpy(), rtol=2e-4, atol=1e-9, err_msg=name)
+    # the one-launch value kernel == the scalar arithmetic it replaces, to the bit
+    from seunet_amd.losses import _value, _value_dev
+    sums = (torch.rand(2, 7, dtype=torch.float64, generator=g) * 1000).cuda()
+    for c0, c1 in (((1.0, 0.0, 0.0), (1.0, 0.0, 0.0)), ((0.0, 1.0, 0.5), (0.0, 0.5, 0.5)), ((0.3, 0.0, 2.0), (0.0, 0.0, 0.0))):
+        assert torch.equal(_value_dev(sums[0], c0), _value(sums[0], *c0))
+        assert torch.equal(_value_dev(sums[0], c0, sums[1], c1), _value(sums[0], *c0) + _value(sums[1], *c1))
     for stage in (1, 2, 3):
         a = logit.clone().requires_grad_(True)
         b = (logit * 0.5 + 0.1).clone().requires_grad_(True)
