@@ -86,6 +86,10 @@ struct MarchArgs {
 };
 
 static constexpr int MA_TX = 32, MA_NW = 4, MA_HXP = 36, MA_PF = 2, MA_RING = 3;
+#ifndef SEUNET_MARCH_PFD
+#define SEUNET_MARCH_PFD 1
+#endif
+static constexpr int MA_PFD = SEUNET_MARCH_PFD;   // fragment prefetch distance in units
 
 template <int KS, int NGW, int RYW, int DIL, int MODE> struct MarchGeo {
   static constexpr int RGW = MA_NW / NGW, RY = RYW * RGW;
@@ -335,22 +339,25 @@ conv_march_kernel(MarchArgs a) {
     constexpr int PH = decltype(ph_c)::value;
     constexpr int NU = HYW * KS * 3;
     const unsigned char* pl = smem + slot * PLB;
-    mbf16x8 fr[2][2];
+    // fragments are requested PFD units ahead of their MFMAs (2 was measured: no change on any layer, the waves do not wait
+    // for fragments -- SQ_WAIT_INST_LDS is 1 % of the wave cycles)
+    constexpr int PFD = MA_PFD;
+    mbf16x8 fr[PFD + 1][2];
     auto load_unit = [&](auto u_c) __attribute__((always_inline)) {
       constexpr int u = decltype(u_c)::value;
       if constexpr (u < NU) {
         constexpr int hi = u / (3 * KS), ks = (u / 3) % KS, dx = u % 3;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          fr[u & 1][b] = *reinterpret_cast<const mbf16x8*>(pl + foff[ks][dx][b] + hi * ROWB);
+          fr[u % (PFD + 1)][b] = *reinterpret_cast<const mbf16x8*>(pl + foff[ks][dx][b] + hi * ROWB);
       }
     };
-    load_unit(std::integral_constant<int, 0>{});
+    static_for<PFD>([&](auto k_c) __attribute__((always_inline)) { load_unit(k_c); });
     if constexpr (MODE == 2) dma_old(s + 1, (s + 1) & 1);   // (first in the step: the wait at the top of step s + 1 counts on it)
     static_for<NU>([&](auto u_c) __attribute__((always_inline)) {
       constexpr int u = decltype(u_c)::value;
       constexpr int hi = u / (3 * KS), ks = (u / 3) % KS, dx = u % 3;
-      load_unit(std::integral_constant<int, u + 1>{});
+      load_unit(std::integral_constant<int, u + PFD>{});
       static_for<ITEMS>([&](auto it_c) __attribute__((always_inline)) {
         constexpr int it = decltype(it_c)::value;
         if constexpr ((it * NU) / ITEMS == u) dma_item(s + MA_PF, slot_pf, it_c);
@@ -376,11 +383,11 @@ conv_march_kernel(MarchArgs a) {
             const int ai = (PH - dz + 3) % 3;
             const int tap = (dz * 3 + dy) * 3 + dx;
 #ifndef SEUNET_MARCH_ASM_MFMA
-            if (dz == 0 && dy == 0 && dx == 0 && ks == 0) acc[ai][r][b] = mm16b<T>(wreg[tap * KS + ks], fr[u & 1][b], cinit);
-            else acc[ai][r][b] = mm16b<T>(wreg[tap * KS + ks], fr[u & 1][b], acc[ai][r][b]);
+            if (dz == 0 && dy == 0 && dx == 0 && ks == 0) acc[ai][r][b] = mm16b<T>(wreg[tap * KS + ks], fr[u % (PFD + 1)][b], cinit);
+            else acc[ai][r][b] = mm16b<T>(wreg[tap * KS + ks], fr[u % (PFD + 1)][b], acc[ai][r][b]);
 #else
-            if (dz == 0 && dy == 0 && dx == 0 && ks == 0) mm16_init<T, 0, MODE == 0>(acc[ai][r][b], wreg[tap * KS + ks], fr[u & 1][b], cinit);
-            else mm16_acc<T, (ks == 1)>(acc[ai][r][b], wreg[tap * KS + ks], fr[u & 1][b]);
+            if (dz == 0 && dy == 0 && dx == 0 && ks == 0) mm16_init<T, 0, MODE == 0>(acc[ai][r][b], wreg[tap * KS + ks], fr[u % (PFD + 1)][b], cinit);
+            else mm16_acc<T, (ks == 1)>(acc[ai][r][b], wreg[tap * KS + ks], fr[u % (PFD + 1)][b]);
 #endif
           }
         }
