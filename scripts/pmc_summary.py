@@ -75,7 +75,12 @@ for key in fetch:
                 print("%-90s %10s %12.3e %12.3e %10.3f   (%s)" % (key[0], "dc5", avg(mv), avg(bv), avg(mv) / avg(bv), tag))
 for key in fetch:
     name, items, wg = key
-    if "wgrad_kernel" in name and "stream" not in name and ("Li27ELi1E" in name or ", 27, 1" in name) and items == 256 * 2 * 256:
+    # the weight gradient of dc5: the tiled kernel (round 2; 512 persistent workgroups) or the marching kernel
+    # wgrad_march_kernel<T, 4, 2, 1> (round 3; 256 workgroups, shared with dc4) -- in both cases the first launch of a step
+    tiled = "wgrad_kernel" in name and "stream" not in name and ("Li27ELi1E" in name or ", 27, 1" in name) and items == 256 * 2 * 256
+    n_ = name.replace(" ", "")
+    march = "wgrad_march_kernel" in n_ and ("Li4ELi2ELi1E" in n_ or ",4,2,1>" in n_) and items == 256 * 256
+    if tiled or march:
         f = avg(first_of_each_step(fetch[key].get("FETCH_SIZE", []))) * 1024 * 2
         w = avg(first_of_each_step(write[key].get("WRITE_SIZE", []))) * 1024
         groups["wgrad:dc5"] = (f, w)

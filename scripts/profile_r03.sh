@@ -11,7 +11,7 @@ ARGS="--steps 10 --warmup 3"
 timeout -k 10 500 python3 bench.py $ARGS --config window512 --dump-kernels $O/bench_launch_groups.tsv > $O/bench.json 2> $O/bench.err
 echo "bench done"; tail -c 300 $O/bench.json
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o seunet -- python3 bench.py $ARGS --no-cpu-baseline --no-secondary --no-kernel-timing > $O/trace.log 2>&1
-python3 scripts/trace_by_grid.py $O/trace/seunet_kernel_trace.csv conv_march_kernel conv_igemm_kernel wgrad_kernel conv_stream_kernel wgrad_stream_kernel > $O/conv_by_grid.txt
+python3 scripts/trace_by_grid.py $O/trace/seunet_kernel_trace.csv conv_march_kernel wgrad_march_kernel conv_igemm_kernel wgrad_kernel conv_stream_kernel wgrad_stream_kernel > $O/conv_by_grid.txt
 cp $O/trace/seunet_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || true
 echo "trace done"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
