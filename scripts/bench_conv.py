@@ -118,4 +118,26 @@ for name, split, cout, dil, size in CASES:
         err = float((dw - ref_dw).abs().max()) / float(ref_dw.abs().max())
         ms = timeit(lambda: wgrad(2))
         res.append("MARCH wgrad %.3f ms %.0f TF/s (rel diff %.1e)" % (ms, flops / ms / 1e9, err))
+    # the streaming kernels (csrc/conv_stream.hip, wgrad_stream.hip) on the same operands, where they serve the shape
+    if TAPS == 27 and len(split) == 1 and lib.seunet_conv3d_stream_supported(code, dil, cin, cout) and "fwd" in which:
+        ws_ = torch.empty(lib.seunet_conv3d_stream_wpack_bytes(cin), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.seunet_conv3d_stream_pack(code, w.data_ptr(), cin, cout, 0, cin, cout, ws_.data_ptr(), _lib.stream_ptr()))
+        sslots = lib.seunet_conv3d_stream_slots(dil, dims)
+        sstats = torch.zeros((B, sslots, cout, 2), dtype=torch.float64, device="cuda")
+        out_s = torch.empty_like(out)
+        sb = torch.zeros(cout, device="cuda")
+        def sfwd():
+            _lib.check(lib.seunet_conv3d_stream(code, dil, srcs[0].data_ptr(), cin, ws_.data_ptr(), sb.data_ptr(), out_s.data_ptr(), cout, 0,
+                                                sstats.data_ptr(), dims, _lib.stream_ptr()))
+        ms = timeit(sfwd)
+        res.append("STREAM fwd %.3f ms %.0f TF/s" % (ms, flops / ms / 1e9))
+    if TAPS == 27 and len(split) == 1 and lib.seunet_conv3d_stream_supported(code, dil, cout, cin) and "dgrad" in which:
+        wd_ = torch.empty(lib.seunet_conv3d_stream_wpack_bytes(cout), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.seunet_conv3d_stream_pack(code, w.data_ptr(), cin, cout, 1, cout, cin, wd_.data_ptr(), _lib.stream_ptr()))
+        g_s = torch.zeros_like(srcs[0])
+        def sdgrad():
+            _lib.check(lib.seunet_conv3d_stream(code, dil, dy.data_ptr(), cout, wd_.data_ptr(), None, g_s.data_ptr(), cin, 1,
+                                                None, dims, _lib.stream_ptr()))
+        ms = timeit(sdgrad)
+        res.append("STREAM dgrad+= %.3f ms %.0f TF/s" % (ms, flops / ms / 1e9))
     print("%-4s %s->%d d%d @%d^3 B%d: " % (name, split, cout, dil, size, B) + " | ".join(res), flush=True)

@@ -193,21 +193,29 @@ conv_march_kernel(MarchArgs a) {
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
   const unsigned char* src0_n = reinterpret_cast<const unsigned char*>(a.src0) + (long long)n * a.D * plane_bytes;
   const unsigned char* src1_n = reinterpret_cast<const unsigned char*>(a.nsrc > 1 ? a.src1 : a.src0) + (long long)n * a.D * plane_bytes;
-  // plane of step s -> ring slot; every wave issues exactly ITEMS instructions (the vmcnt arithmetic counts on it)
-  auto dma_item = [&](int s, int slot, auto it_c) __attribute__((always_inline)) {
+  // plane of step s -> ring slot; every wave issues exactly ITEMS instructions (the vmcnt arithmetic counts on it).  The
+  // plane-level part (validity, 64-bit plane bases, LDS slot base) is computed once per step (`plane_of`) and handed to the
+  // items: they sit in different scheduling regions, so the compiler recomputed it for each of them, and with one wave per
+  // SIMD every scalar instruction takes an issue slot from the MFMA stream
+  struct PlaneRef { const unsigned char* b0; const unsigned char* b1; unsigned lds; bool ok; };
+  auto plane_of = [&](int s, int slot) __attribute__((always_inline)) -> PlaneRef {
+    PlaneRef r;
+    const int pl = q0 - 1 + s;
+    const int z = pz + DIL * pl;
+    r.ok = pl >= 0 && z < a.D && s < ncompute;                     // wave-uniform
+    const long long zb = (long long)(r.ok ? z : 0) * plane_bytes;  // (scalar)
+    r.b0 = src0_n + zb; r.b1 = src1_n + zb;
+    r.lds = lds_base + (unsigned)(slot * PLB);
+    return r;
+  };
+  auto dma_item = [&](const PlaneRef& r, auto it_c) __attribute__((always_inline)) {
     constexpr int it = decltype(it_c)::value;
     if constexpr (it < ITEMS) {
       const bool real = wave + MA_NW * it < NI;                     // wave-uniform
-      const int pl = q0 - 1 + s;
-      const int z = pz + DIL * pl;
-      const bool zok = real && pl >= 0 && z < a.D && s < ncompute;  // wave-uniform
-      const long long zb = (long long)(zok ? z : 0) * plane_bytes;  // (scalar)
       const unsigned d = doff[it];
-      const unsigned char* b0 = src0_n + zb;
-      const unsigned char* b1 = src1_n + zb;
-      const unsigned char* gp = ((d & 0x80000000u) ? b1 : b0) + (d & 0x7FFFFFFFu);
-      gp = (zok && d != 0xFFFFFFFFu) ? gp : zero_page;
-      march_dma16(gp, real ? lds_base + (unsigned)(slot * PLB + (wave + MA_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
+      const unsigned char* gp = ((d & 0x80000000u) ? r.b1 : r.b0) + (d & 0x7FFFFFFFu);
+      gp = (r.ok && real && d != 0xFFFFFFFFu) ? gp : zero_page;
+      march_dma16(gp, real ? r.lds + (unsigned)((wave + MA_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
     }
   };
 
@@ -339,6 +347,7 @@ conv_march_kernel(MarchArgs a) {
     constexpr int PH = decltype(ph_c)::value;
     constexpr int NU = HYW * KS * 3;
     const unsigned char* pl = smem + slot * PLB;
+    const PlaneRef pref = plane_of(s + MA_PF, slot_pf);
     // fragments are requested PFD units ahead of their MFMAs (2 was measured: no change on any layer, the waves do not wait
     // for fragments -- SQ_WAIT_INST_LDS is 1 % of the wave cycles)
     constexpr int PFD = MA_PFD;
@@ -360,7 +369,7 @@ conv_march_kernel(MarchArgs a) {
       load_unit(std::integral_constant<int, u + PFD>{});
       static_for<ITEMS>([&](auto it_c) __attribute__((always_inline)) {
         constexpr int it = decltype(it_c)::value;
-        if constexpr ((it * NU) / ITEMS == u) dma_item(s + MA_PF, slot_pf, it_c);
+        if constexpr ((it * NU) / ITEMS == u) dma_item(pref, it_c);
       });
       if constexpr (ks == KS - 1 && dx >= 1) {
         if constexpr (hi + 1 < RYW)
@@ -417,7 +426,8 @@ conv_march_kernel(MarchArgs a) {
   // slot (plane s - 1) that this step's prefetch overwrites.
   static_for<MA_PF>([&](auto k_c) __attribute__((always_inline)) {
     constexpr int k = decltype(k_c)::value;
-    static_for<ITEMS>([&](auto it_c) __attribute__((always_inline)) { dma_item(k, k, it_c); });
+    const PlaneRef r = plane_of(k, k);
+    static_for<ITEMS>([&](auto it_c) __attribute__((always_inline)) { dma_item(r, it_c); });
   });
   march_wait_vm<(MA_PF - 1) * ITEMS>();    // plane 0 has landed (this wave's part)
   __builtin_amdgcn_s_barrier();

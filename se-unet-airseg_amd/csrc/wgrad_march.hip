@@ -213,25 +213,36 @@ wgrad_march_kernel(WmArgs a) {
 
     // DMA instruction `it` of the planes of step s (X plane -> slot xs, dY plane s -> slot ys); every wave issues exactly TOT
     // instructions per step (padding instructions land in the dump area)
-    auto issue_item = [&](int s, int xs, int ys, auto it_c) __attribute__((always_inline)) {
+    // (the plane-level part -- validity, 64-bit plane base, LDS slot base -- is computed ONCE per step by `plane_of` and handed
+    // to the items: with one wave per SIMD every scalar instruction takes an issue slot from the MFMA stream, and the items
+    // sit in different scheduling regions, so the compiler recomputed it for each of them)
+    struct PlaneRef { const unsigned char* x0; const unsigned char* x1; const unsigned char* y; unsigned xlds, ylds; bool xok, yok; };
+    auto plane_of = [&](int s, int xs, int ys) __attribute__((always_inline)) -> PlaneRef {
+      PlaneRef r;
+      const int pl = q0 - 1 + s;
+      const int z = pz + DIL * pl;
+      r.xok = pl >= 0 && z < a.D && s < nsteps;                       // wave-uniform
+      const long long zb = (long long)(r.xok ? z : 0) * xplane;
+      r.x0 = x0_n + zb; r.x1 = x1_n + zb;
+      r.yok = s < Z;                                                  // wave-uniform
+      r.y = dy_n + (long long)(r.yok ? pz + DIL * (q0 + s) : 0) * yplane;
+      r.xlds = lds_base + (unsigned)(xs * PLBX);
+      r.ylds = lds_base + (unsigned)(Geo::YOFF + ys * PLBY);
+      return r;
+    };
+    auto issue_item = [&](const PlaneRef& r, auto it_c) __attribute__((always_inline)) {
       constexpr int it = decltype(it_c)::value;
       if constexpr (it < ITEMSX) {
-        const int pl = q0 - 1 + s;
-        const int z = pz + DIL * pl;
-        const bool zok = pl >= 0 && z < a.D && s < nsteps;            // wave-uniform
-        const long long zb = (long long)(zok ? z : 0) * xplane;
         const bool real = wave + WM_NW * it < NIX;                    // wave-uniform
         const unsigned d = dox[it];
-        const unsigned char* gp = ((d & 0x80000000u) ? x1_n : x0_n) + zb + (d & 0x7FFFFFFFu);
-        gp = (zok && d != 0xFFFFFFFFu) ? gp : zero_page;
-        wm_dma16(gp, real ? lds_base + (unsigned)(xs * PLBX + (wave + WM_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
+        const unsigned char* gp = ((d & 0x80000000u) ? r.x1 : r.x0) + (d & 0x7FFFFFFFu);
+        gp = (r.xok && d != 0xFFFFFFFFu) ? gp : zero_page;
+        wm_dma16(gp, real ? r.xlds + (unsigned)((wave + WM_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
       } else {
         constexpr int iy = it - ITEMSX;
-        const bool zok = s < Z;                                       // wave-uniform
-        const long long zb = (long long)(zok ? pz + DIL * (q0 + s) : 0) * yplane;
         const unsigned d = doy[iy];
-        const unsigned char* gp = (zok && d != 0xFFFFFFFFu) ? dy_n + zb + d : zero_page;
-        wm_dma16(gp, zok ? lds_base + (unsigned)(Geo::YOFF + ys * PLBY + (wave + WM_NW * iy) * 1024) : lds_base + (unsigned)Geo::DUMP);
+        const unsigned char* gp = (r.yok && d != 0xFFFFFFFFu) ? r.y + d : zero_page;
+        wm_dma16(gp, r.yok ? r.ylds + (unsigned)((wave + WM_NW * iy) * 1024) : lds_base + (unsigned)Geo::DUMP);
       }
     };
 
@@ -301,8 +312,11 @@ wgrad_march_kernel(WmArgs a) {
     wm_wait_vm<0>();
     __syncthreads();                     // the previous item's readers are done; the zero plane is written
     if (nsteps == 0) continue;           // (block-uniform)
-    wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) { issue_item(0, 0, 0, it_c); });
-    wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) { issue_item(1, 1, 1, it_c); });
+    {
+      const PlaneRef p0 = plane_of(0, 0, 0), p1 = plane_of(1, 1, 1);
+      wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) { issue_item(p0, it_c); });
+      wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) { issue_item(p1, it_c); });
+    }
     wm_wait_vm<TOT>();
     __builtin_amdgcn_s_barrier();
     int xs = 0, ys = 0;                  // ring slots of step s: s % 3, s % 5
@@ -311,12 +325,13 @@ wgrad_march_kernel(WmArgs a) {
     for (int s = 0; s < nsteps; ++s) {
       const int xs2 = xs + 2 >= WM_XRING ? xs + 2 - WM_XRING : xs + 2;
       const int ys2 = ys + 2 >= WM_YRING ? ys + 2 - WM_YRING : ys + 2;
+      const PlaneRef pr = plane_of(s + 2, xs2, ys2);
       wm_for<HY - 1>([&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         row(i_c, std::integral_constant<int, i + 1>{}, [&]() __attribute__((always_inline)) {
           wm_for<TOT>([&](auto it_c) __attribute__((always_inline)) {
             constexpr int it = decltype(it_c)::value;
-            if constexpr ((it * (HY - 1)) / TOT == i) issue_item(s + 2, xs2, ys2, it_c);
+            if constexpr ((it * (HY - 1)) / TOT == i) issue_item(pr, it_c);
           });
         });
       });
