@@ -19,6 +19,12 @@
 
 namespace seunet {
 
+// the value a store of type T keeps (round to nearest even for the 16-bit types, the same conversion store8 uses)
+template <typename T> __device__ __forceinline__ float round_to(float v) {
+  if constexpr (sizeof(T) == 4) return v;
+  else return unpack_lo<T>(pack2<T>(v, 0.f));
+}
+
 static constexpr int EPI_THREADS = 256;
 
 int epi_partials(Dims d) {
@@ -888,7 +894,8 @@ template <typename T, int LPV>
 __global__ void __launch_bounds__(EPI_THREADS)
 cat_fwd_pool_kernel(const T* __restrict__ raw, const float* __restrict__ mean, const float* __restrict__ rstd,
                     const T* __restrict__ xin, const float* __restrict__ mean2, const float* __restrict__ rstd2, int C, float slope,
-                    T* __restrict__ out, T* __restrict__ pooled, int D, int H, int W, const float* __restrict__ w2x, int xic) {
+                    T* __restrict__ out, T* __restrict__ pooled, int D, int H, int W, const float* __restrict__ w2x, int xic,
+                    unsigned* __restrict__ argmax) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
   constexpr int VPB = EPI_THREADS / LPV;
@@ -917,6 +924,7 @@ cat_fwd_pool_kernel(const T* __restrict__ raw, const float* __restrict__ mean, c
       load8p(xin + ((long long)n * V + v) * 8, pi[k]);
     }
     float m[8];
+    unsigned am = 0;      // 3 bits per channel: the window position (z, y, x scan order) of the FIRST maximum of the STORED values
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
 #pragma unroll
@@ -937,22 +945,28 @@ cat_fwd_pool_kernel(const T* __restrict__ raw, const float* __restrict__ mean, c
         y[j] += xh > 0.f ? xh : xh * slope;
       }
       store8(out + ((long long)n * V + v) * C + c0, y);
+      // the maximum (and its position) of the values as stored: what a max-pool over the stored tensor sees (two different f32
+      // values may round to the same 16-bit value; the reference's first-maximum rule then picks the earlier one)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = y[j] > m[j] ? y[j] : m[j];   // (rounded once by the store below, like the values above)
+      for (int j = 0; j < 8; ++j) {
+        const float yr = round_to<T>(y[j]);
+        if (yr > m[j]) { m[j] = yr; am = (am & ~(7u << (3 * j))) | ((unsigned)k << (3 * j)); }
+      }
     }
     store8(pooled + ((long long)n * Vo + cv) * C + c0, m);
+    if (argmax != nullptr) argmax[((long long)n * Vo + cv) * (C / 8) + cg] = am;
   }
 }
 
 int launch_cat_fwd_x_pool(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
                           int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, void* pooled,
-                          Dims d, hipStream_t s) {
+                          Dims d, hipStream_t s, unsigned* argmax) {
   if (int e = check_c(C)) return e;
   SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_epilogue_fwd_x_pool: in_channel %d (1 or 2)", in_channel);
   SEUNET_CHECK(d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0, "cat_epilogue_fwd_x_pool: odd extent");
   dim3 grid(epi_partials(d) * 4, d.N);
   SEUNET_LPV_SWITCH(C / 8, {
-    SEUNET_DTYPE_SWITCH(dtype, cat_fwd_pool_kernel<T, LPV><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, (T*)out, (T*)pooled, d.D, d.H, d.W, w2, in_channel));
+    SEUNET_DTYPE_SWITCH(dtype, cat_fwd_pool_kernel<T, LPV><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, (T*)out, (T*)pooled, d.D, d.H, d.W, w2, in_channel, argmax));
   });
   SEUNET_LAUNCH_CHECK();
   return 0;

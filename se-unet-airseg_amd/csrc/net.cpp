@@ -137,6 +137,7 @@ struct OpRes {
   bool need_dgrad = false;
   bool stream_f = false, stream_d = false, stream_w = false;   // forward / data gradient / weight gradient on the streaming kernels
   bool march_f = false, march_d = false;                       // forward / data gradient on the marching kernel (conv_march.hip)
+  size_t pool_idx = 0; bool has_pool_idx = false;              // OP_POOL behind a fused aggregation block: arg-max words of the forward
 };
 
 struct Plan {
@@ -183,6 +184,14 @@ struct Plan {
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
       OpRes& r = op[i];
+      if (o.kind == OP_POOL && i > 0 && kOps[i - 1].kind == OP_CAT && kOps[i - 1].xname && kOps[i - 1].dst == o.src[0] &&
+          d.in_channel <= 2 && d.conv_impl != SEUNET_CONV_NAIVE && !is_input(o.src[0])) {
+        // the aggregation block's forward writes this pool (and the position of each maximum, which the backward pass then
+        // reads instead of the block output and the pooled tensor)
+        const Dims& dl = dims[kT[o.dst].level];
+        r.pool_idx = take((size_t)d.batch * dl.vox() * (C[o.src[0]] / 8) * 4);
+        r.has_pool_idx = true;
+      }
       if (o.kind == OP_POOL || o.kind == OP_UP) continue;
       const int lv = kT[o.dst].level;
       r.cout = C[o.dst];
@@ -442,7 +451,8 @@ struct Exec {
           if (pool_next) {
             if (int e = launch_cat_fwd_x_pool(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), at(p.feat[o.xsrc]), w2, p.d.in_channel,
                                               fat(r.mean2), fat(r.rstd2), r.cout, p.d.negative_slope, at(p.feat[o.dst]),
-                                              at(p.feat[kOps[i + 1].dst]), p.dims[lv], s)) return e;
+                                              at(p.feat[kOps[i + 1].dst]), p.dims[lv], s,
+                                              p.op[i + 1].has_pool_idx ? reinterpret_cast<unsigned*>(at(p.op[i + 1].pool_idx)) : nullptr)) return e;
             pool_done[i + 1] = true;
           } else if (int e = launch_cat_fwd_x(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), at(p.feat[o.xsrc]), w2, p.d.in_channel,
                                        fat(r.mean2), fat(r.rstd2), r.cout, p.d.negative_slope, at(p.feat[o.dst]), p.dims[lv], s)) return e;
@@ -543,8 +553,12 @@ struct Exec {
         SEUNET_CHECK(written[o.dst], "net: internal: gradient of %s output missing", o.name);
         mark((o.kind == OP_POOL ? "pool_bwd:" : "up_bwd:") + n);
         if (o.kind == OP_POOL) {
-          if (int e = launch_maxpool_bwd(p.d.dtype, at(p.feat[t]), at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
-                                         p.dims[kT[t].level], s)) return e;
+          // (the index is valid when the fused forward wrote it: same condition as in the forward walk)
+          if (r.has_pool_idx && getenv("SEUNET_NO_POOL_FUSE") == nullptr) {
+            if (int e = launch_maxpool_bwd_idx(p.d.dtype, reinterpret_cast<const unsigned*>(at(r.pool_idx)), at(p.grad[o.dst]), p.C[t],
+                                               at(p.grad[t]), written[t] ? 1 : 0, p.dims[kT[t].level], s)) return e;
+          } else if (int e = launch_maxpool_bwd(p.d.dtype, at(p.feat[t]), at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
+                                                p.dims[kT[t].level], s)) return e;
         } else {
           if (int e = launch_upsample2_bwd(p.d.dtype, at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
                                            p.dims[kT[t].level], s)) return e;

@@ -322,7 +322,7 @@ int launch_cat_fwd_x(int dtype, const void* raw, const float* mean, const float*
                      hipStream_t s);
 int launch_cat_fwd_x_pool(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
                           int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, void* pooled,
-                          Dims d, hipStream_t s);
+                          Dims d, hipStream_t s, unsigned* argmax = nullptr);
 int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,
                      const float* w2, int in_channel, const float* mean2, const float* rstd2, int C, float slope,
                      const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, double* stat_partial,
@@ -330,6 +330,8 @@ int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float*
 int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_channel, float* dw, hipStream_t s);
 int launch_xbranch_values(int dtype, const void* x_in, const float* w2, int C, int in_channel, float* out_ncdhw, Dims d, hipStream_t s);   // diagnostic
 int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);
+// max-pool backward from the arg-max words written by launch_cat_fwd_x_pool ([N][Vo][C/8] uint32, 3 bits per channel)
+int launch_maxpool_bwd_idx(int dtype, const unsigned* argmax, const void* g_out, int C, void* g_in, int accumulate, Dims d, hipStream_t s);
 int launch_maxpool_bwd(int dtype, const void* in, const void* g_out, int C, void* g_in,
                        int accumulate, Dims din, hipStream_t s);
 int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);
