@@ -566,6 +566,33 @@ cat_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   }
 }
 
+// The gradient that arrives through the 2x2x2 max-pool consuming this block's output (encoder: ec33 -> pool0, ec63 -> pool1,
+// ec93 -> pool2) is added ON THE FLY in both passes instead of being scattered into g_out by a pooling-backward kernel first
+// (a read-modify-write of the whole full-resolution gradient): window word of arg-max positions (cat_fwd_pool_kernel) + the
+// pooled gradient, 20 bytes per voxel and 8 channels, shared by the eight voxels of a window through the caches.
+struct PoolRef {
+  const unsigned* argmax;     // [N][Vo][C/8], 3 bits per channel; null = no pool gradient
+  const void* g_pool;         // [N][Vo][C]
+  unsigned W, H, Wo, Ho;      // extents of THIS block's level, and of the pooled level
+  unsigned mW, mH;            // floor(2^32 / W), floor(2^32 / H)
+  long long Vo;
+};
+__device__ __forceinline__ unsigned div_small(unsigned n, unsigned d, unsigned m, unsigned& rem) {
+  unsigned q = __umulhi(n, m);            // q <= n / d <= q + 1
+  unsigned r = n - q * d;
+  if (r >= d) { ++q; r -= d; }
+  rem = r;
+  return q;
+}
+// window position (0..7, z-y-x scan order) of voxel v and the index of its window
+__device__ __forceinline__ void pool_locate(const PoolRef& pr, unsigned v, unsigned& kpos, unsigned& cv) {
+  unsigned x, y;
+  const unsigned t = div_small(v, pr.W, pr.mW, x);
+  const unsigned z = div_small(t, pr.H, pr.mH, y);
+  kpos = ((z & 1u) << 2) | ((y & 1u) << 1) | (x & 1u);
+  cv = ((z >> 1) * pr.Ho + (y >> 1)) * pr.Wo + (x >> 1);
+}
+
 // APPLY = false: per-(n,c) f64 sums of dxhat, dxhat*xhat for one or two branches (nothing stored)
 // APPLY = true : draw = rstd * (dxhat - m1 - xhat * m2) for each branch (dxhat_out may alias g_out)
 // XW (pass B of a two-branch block whose second branch is a 1x1x1 conv of the <= 2-channel network input, the x33 / x63 /
@@ -582,11 +609,14 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
                T* dxhat2_out, double* __restrict__ stat_partial,
                double* __restrict__ stat_partial2, long long V,
                const T* __restrict__ xin = nullptr, float* __restrict__ xw_partial = nullptr,
-               const float* __restrict__ w2x = nullptr, int xic = 0) {
+               const float* __restrict__ w2x = nullptr, int xic = 0, PoolRef pool = PoolRef{}) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
   constexpr int VPB = EPI_THREADS / LPV;
   const int c0 = cg * 8;
+  const bool pooled = pool.argmax != nullptr;                       // (uniform)
+  const unsigned* pam = pool.argmax + (long long)n * pool.Vo * (C / 8) + cg;
+  const T* pgp = reinterpret_cast<const T*>(pool.g_pool) + (long long)n * pool.Vo * C + c0;
   float mu[8], rs[8], mu2[8], rs2[8], a1[8], a2[8], b1[8], b2[8];
   typedef typename std::conditional<sizeof(T) == 2, float, double>::type SumT;   // (bf16: f32 thread sums, see sse_bwd_kernel)
   SumT s[4][8];
@@ -610,13 +640,21 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
   }
   const long long stride = (long long)P * VPB;
   long long v = (long long)blockIdx.x * VPB + vb;
-  Pack8<T> ng, nx, nx2;   // software pipeline: voxel v + stride is loaded before voxel v is computed
-  zero8p(ng); zero8p(nx); zero8p(nx2);
+  Pack8<T> ng, nx, nx2, npg;   // software pipeline: voxel v + stride is loaded before voxel v is computed
+  unsigned nam = 0, nkpos = 0;
+  zero8p(ng); zero8p(nx); zero8p(nx2); zero8p(npg);
+  auto fetch_pool = [&](long long vv) __attribute__((always_inline)) {
+    unsigned cv;
+    pool_locate(pool, (unsigned)vv, nkpos, cv);
+    nam = pam[(long long)cv * (C / 8)];
+    load8p(pgp + (long long)cv * C, npg);
+  };
   if (v < V) {
     const long long o = ((long long)n * V + v) * C + c0;
     load8p(g_out + o, ng);
     load8p(raw + o, nx);
     if (TWO) load8p(XR ? raw2 + ((long long)n * V + v) * 8 : raw2 + o, nx2);
+    if (pooled) fetch_pool(v);
   }
   for (; v < V; v += stride) {
     const long long o = ((long long)n * V + v) * C + c0;
@@ -624,10 +662,17 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
     unpack8(ng, gy);
     unpack8(nx, x);
     if (TWO) { unpack8(nx2, in2); second_branch<XR>(in2, wa, wb, x2); }
+    if (pooled) {           // + the pooled gradient where this voxel was its window's maximum
+      float gp[8];
+      unpack8(npg, gp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gy[j] += ((nam >> (3 * j)) & 7u) == nkpos ? gp[j] : 0.f;
+    }
     if (v + stride < V) {   // a later voxel of this same thread: never written by anyone before it is read
       load8p(g_out + o + stride * C, ng);
       load8p(raw + o + stride * C, nx);
       if (TWO) load8p(XR ? raw2 + ((long long)n * V + v + stride) * 8 : raw2 + o + stride * C, nx2);
+      if (pooled) fetch_pool(v + stride);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -977,17 +1022,26 @@ int launch_cat_fwd_x_pool(int dtype, const void* raw, const float* mean, const f
 int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,
                      const float* w2, int in_channel, const float* mean2, const float* rstd2, int C, float slope,
                      const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, double* stat_partial,
-                     double* stat_partial2, float* xw_partial, Dims d, hipStream_t s) {
+                     double* stat_partial2, float* xw_partial, Dims d, hipStream_t s, const unsigned* pool_argmax, const void* pool_g) {
   if (int e = check_c(C)) return e;
   SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_epilogue_bwd_x: in_channel %d (1 or 2)", in_channel);
+  PoolRef pr{};
+  if (pool_argmax != nullptr) {
+    SEUNET_CHECK(pool_g != nullptr && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0 && d.vox() < (1ll << 31),
+                 "cat_epilogue_bwd_x: pooled gradient needs even extents below 2^31 voxels");
+    pr.argmax = pool_argmax; pr.g_pool = pool_g;
+    pr.W = (unsigned)d.W; pr.H = (unsigned)d.H; pr.Wo = (unsigned)d.W / 2; pr.Ho = (unsigned)d.H / 2;
+    pr.mW = (unsigned)((1ull << 32) / (unsigned)d.W); pr.mH = (unsigned)((1ull << 32) / (unsigned)d.H);
+    pr.Vo = d.vox() / 8;
+  }
   const bool apply = m1 != nullptr;
   if (!apply) SEUNET_CHECK(stat_partial && stat_partial2, "cat_epilogue_bwd_x pass A needs the partial buffers");
   else SEUNET_CHECK(m2 && m1b && m2b && dx && xw_partial, "cat_epilogue_bwd_x pass B: missing argument");
   dim3 grid(epi_partials(d) * (apply ? 4 : 1), d.N);
   SEUNET_LPV_SWITCH(C / 8, {
     SEUNET_DTYPE_SWITCH(dtype, {
-      if (apply) cat_bwd_kernel<T, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (T*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel);
-      else cat_bwd_kernel<T, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel);
+      if (apply) cat_bwd_kernel<T, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (T*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel, pr);
+      else cat_bwd_kernel<T, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel, pr);
     });
   });
   SEUNET_LAUNCH_CHECK();

@@ -538,6 +538,8 @@ struct Exec {
     }
     std::vector<float*> zero_ptrs;
     std::vector<int> zero_counts;
+    const unsigned* pool_am[T_COUNT] = {};     // per tensor: a max-pool gradient still to be added by its producer's backward
+    const void* pool_g[T_COUNT] = {};
     for (int i = kNumOps - 1; i >= 0; --i) {
       const OpDesc& o = kOps[i];
       const OpRes& r = p.op[i];
@@ -554,7 +556,15 @@ struct Exec {
         mark((o.kind == OP_POOL ? "pool_bwd:" : "up_bwd:") + n);
         if (o.kind == OP_POOL) {
           // (the index is valid when the fused forward wrote it: same condition as in the forward walk)
-          if (r.has_pool_idx && getenv("SEUNET_NO_POOL_FUSE") == nullptr) {
+          static const bool no_fuse = getenv("SEUNET_NO_POOL_FUSE") != nullptr, no_defer = getenv("SEUNET_NO_POOL_DEFER") != nullptr;
+          if (r.has_pool_idx && !no_fuse && !no_defer && written[t] && p.fuse_x) {
+            // nothing to launch: the aggregation block that produced tensor t adds this gradient on the fly in both of its
+            // backward passes (launch_cat_bwd_x, pool_* arguments) -- no read-modify-write of the full-resolution gradient
+            pool_am[t] = reinterpret_cast<const unsigned*>(at(r.pool_idx));
+            pool_g[t] = at(p.grad[o.dst]);
+            continue;
+          }
+          if (r.has_pool_idx && !no_fuse) {
             if (int e = launch_maxpool_bwd_idx(p.d.dtype, reinterpret_cast<const unsigned*>(at(r.pool_idx)), at(p.grad[o.dst]), p.C[t],
                                                at(p.grad[t]), written[t] ? 1 : 0, p.dims[kT[t].level], s)) return e;
           } else if (int e = launch_maxpool_bwd(p.d.dtype, at(p.feat[t]), at(p.grad[o.dst]), p.C[t], at(p.grad[t]), written[t] ? 1 : 0,
@@ -605,14 +615,14 @@ struct Exec {
           const void* xin = at(p.feat[o.xsrc]);
           if (int e = launch_cat_bwd_x(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), xin, w2, p.d.in_channel, mu2, rs2,
                                        r.cout, p.d.negative_slope, nullptr, nullptr, nullptr, nullptr, nullptr, dat(p.stats), dat(p.stats2),
-                                       nullptr, dm, s)) return e;
+                                       nullptr, dm, s, pool_am[o.dst], pool_g[o.dst])) return e;
           mark("stats");
           if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
           if (int e = launch_stats_finalize(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
           mark("in_bwd:" + n);    // pass B
           if (int e = launch_cat_bwd_x(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), xin, w2, p.d.in_channel, mu2, rs2,
                                        r.cout, p.d.negative_slope, fat(p.m1), fat(p.m2), fat(p.m1b), fat(p.m2b), at(p.grad[o.dst]), nullptr,
-                                       nullptr, fat(p.xwp), dm, s)) return e;
+                                       nullptr, fat(p.xwp), dm, s, pool_am[o.dst], pool_g[o.dst])) return e;
           if (grads[xi]) {
             mark("stats");
             if (int e = launch_cat_xgrad_reduce(fat(p.xwp), cat_xgrad_records(dm), r.cout, p.d.in_channel, grads[xi], s)) return e;
