@@ -129,23 +129,33 @@ conv_stream_kernel(StreamArgs a) {
     dlds[it] = (unsigned)(p * PS + gi * 1024);
   }
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
-  auto dma_item = [&](int s, int slot, auto it_c) __attribute__((always_inline)) {   // plane of step s -> ring slot `slot` (= s % Geo::RING)
+  // plane of step s -> ring slot `slot` (= s % Geo::RING).  The plane-level part (validity, 64-bit plane base, LDS slot base) is
+  // computed once per step (`plane_of`) and handed to the items: they sit in different scheduling regions, so the compiler
+  // recomputed it for each of them, and these loops are bound by instruction issue
+  struct PlaneRef { const unsigned char* base; unsigned lds; bool ok; };
+  auto plane_of = [&](int s, int slot) __attribute__((always_inline)) -> PlaneRef {
+    PlaneRef r;
+    const int pl = q0 - 1 + s;                                      // plane index in the parity class
+    const int z = pz + DIL * pl;
+    r.ok = pl >= 0 && z < a.D && s < nsteps;                        // wave-uniform
+    r.base = src_n + (long long)(r.ok ? z : 0) * plane_bytes;
+    r.lds = lds_base + (unsigned)(slot * PLANE);
+    return r;
+  };
+  auto dma_item = [&](const PlaneRef& r, auto it_c) __attribute__((always_inline)) {
     constexpr int it = decltype(it_c)::value;
     if constexpr (it < ITEMS) {
       // every wave issues exactly ITEMS instructions per plane (the vmcnt arithmetic of the march counts on it): an item
       // number beyond the plane's NP * G pieces copies the zero page into the dump area
       const bool real = wave + ST_NW * it < NP * G;                 // wave-uniform
-      const int pl = q0 - 1 + s;                                    // plane index in the parity class
-      const int z = pz + DIL * pl;
-      const bool zok = real && pl >= 0 && z < a.D && s < nsteps;    // wave-uniform
-      const unsigned char* base = src_n + (long long)(zok ? z : 0) * plane_bytes;
-      const unsigned char* gp = (zok && doff[it] != 0xFFFFFFFFu) ? base + doff[it] : zero_page;
-      stream_dma16(gp, real ? lds_base + (unsigned)(slot * PLANE) + dlds[it] : lds_base + (unsigned)(Geo::RING * PLANE));
+      const unsigned char* gp = (r.ok && real && doff[it] != 0xFFFFFFFFu) ? r.base + doff[it] : zero_page;
+      stream_dma16(gp, real ? r.lds + dlds[it] : lds_base + (unsigned)(Geo::RING * PLANE));
     }
   };
   auto dma_plane = [&](int s, int slot) __attribute__((always_inline)) {
+    const PlaneRef r = plane_of(s, slot);
     [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
-      (dma_item(s, slot, std::integral_constant<int, I>{}), ...);
+      (dma_item(r, std::integral_constant<int, I>{}), ...);
     }(std::make_integer_sequence<int, ITEMS>{});
   };
 
@@ -225,6 +235,7 @@ conv_stream_kernel(StreamArgs a) {
   auto compute = [&](int s, int slot, int slot_pf, auto ph_c) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_c)::value;
     const unsigned char* pl = smem + slot * PLANE;
+    const PlaneRef pref = plane_of(s + Geo::PF, slot_pf);
     bf16x8 fr[2][NDX][NBX];
     auto load_row = [&](auto ri_c) __attribute__((always_inline)) {
       constexpr int ri = decltype(ri_c)::value;
@@ -239,12 +250,24 @@ conv_stream_kernel(StreamArgs a) {
       }
     };
     load_row(std::integral_constant<int, 0>{});
+    AccT cinit;
+    if constexpr (FWD && COUTP == 32) {   // 16 bias values: four 16-byte reads of the LDS table per step (no registers to keep them)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(smem + Geo::BIAS + (8 * q + 4 * fg) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cinit[4 * q + e] = bq[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < ACCR; ++e) cinit[e] = (FWD && COUTP == 16) ? bias_r[BR == 1 ? 0 : e] : 0.f;
+    }
     [&]<int... RI>(std::integer_sequence<int, RI...>) __attribute__((always_inline)) {
       ([&]() __attribute__((always_inline)) {
         constexpr int ri = RI;                             // input row y = ra + DIL * (ri - 1): tap dy = ri - 1
         load_row(std::integral_constant<int, ri + 1>{});
         [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
-          (((I % 3) == ri ? dma_item(s + Geo::PF, slot_pf, std::integral_constant<int, I>{}) : (void)0), ...);
+          (((I % 3) == ri ? dma_item(pref, std::integral_constant<int, I>{}) : (void)0), ...);
         }(std::make_integer_sequence<int, ITEMS>{});
         if (ri == 2) dma_old(s + Geo::PF, slot_pf);
         __builtin_amdgcn_sched_barrier(0);                 // (the next row's reads stay ahead of this row's MFMAs)
@@ -254,10 +277,13 @@ conv_stream_kernel(StreamArgs a) {
           for (int dz = -1; dz <= 1; ++dz) {               // output plane s - dz
             const int ai = (PH - dz + 3) % 3;
             const int tap = ((dz + 1) * 3 + ri) * NDX + dxi;
+            // the set that the previous step finished starts over here (tap dz = -1 of the first row): its first MFMA takes
+            // the bias vector (forward) / zero as C, so nothing is ever zeroed and the epilogue adds no bias
+            const bool first = dz == -1 && ri == 0 && dxi == 0;
 #pragma unroll
             for (int b = 0; b < NBX; ++b) {
-              if constexpr (COUTP == 32) acc[ai][b] = st_mfma32<T>(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b]);
-              else acc[ai][b] = st_mfma16<T>(wreg[tap], fr[ri & 1][dxi][b], acc[ai][b]);
+              if constexpr (COUTP == 32) acc[ai][b] = st_mfma32<T>(wreg[tap], fr[ri & 1][dxi][b], first ? cinit : acc[ai][b]);
+              else acc[ai][b] = st_mfma16<T>(wreg[tap], fr[ri & 1][dxi][b], first ? cinit : acc[ai][b]);
             }
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -280,12 +306,7 @@ conv_stream_kernel(StreamArgs a) {
         const bool ok = zok && y < a.H && x < a.W;
         float v[ACCR];
 #pragma unroll
-        for (int e = 0; e < ACCR; ++e) {
-          float bv = 0.f;
-          if constexpr (FWD && COUTP == 16) bv = bias_r[BR == 1 ? 0 : e];
-          if constexpr (FWD && COUTP == 32) bv = reinterpret_cast<const float*>(smem + Geo::BIAS)[(e & 3) + 8 * (e >> 2) + 4 * fg];
-          v[e] = acc[ai][b][e] + bv;
-        }
+        for (int e = 0; e < ACCR; ++e) v[e] = acc[ai][b][e];       // (bias included: it was the C operand of the set's first MFMA)
         if constexpr (FWD) {
           if (ok) {                      // (a.stats == nullptr: the sums are simply never stored)
 #pragma unroll
@@ -311,8 +332,6 @@ conv_stream_kernel(StreamArgs a) {
           u.y = pack2<T>(w4[2], w4[3]);
           __builtin_amdgcn_raw_buffer_store_b64(u, rd, off, 0, 0);
         }
-#pragma unroll
-        for (int e = 0; e < ACCR; ++e) acc[ai][b][e] = 0.f;
       }
     }
   };
