@@ -12,6 +12,7 @@ reps = int(os.environ.get("REPS", 5))
 # name, splits, cout, dil, size
 CASES = [("dc5", [32, 32], 32, 1, 128), ("dc3", [64, 64], 64, 1, 64), ("ec3", [16], 32, 2, 128), ("dc6", [32], 16, 1, 128),
          ("ec2", [8], 16, 1, 128), ("ec6", [32], 64, 2, 64), ("dc4", [64], 32, 1, 64), ("ec4", [32], 32, 1, 64), ("ec5", [32], 32, 2, 64),
+         ("ec8", [64], 64, 2, 32), ("dc2", [64], 64, 1, 32), ("dc1", [128, 128], 64, 1, 32), ("ec11", [128], 128, 2, 16),
          # 1x1x1 layers (name ends in "_1"): the x33 / ec33 shortcut convolutions
          ("x33_1", [8], 32, 1, 128), ("ec33_1", [32], 32, 1, 128), ("ec63_1", [64], 64, 1, 64)]
 dt = torch.bfloat16

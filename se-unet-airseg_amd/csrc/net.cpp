@@ -123,9 +123,13 @@ constexpr int kNumOps = sizeof(kOps) / sizeof(kOps[0]);
 
 inline bool is_input(int t) { return t <= T_X2; }
 // levels on which the marching conv pays: full 32-voxel rows and enough (y, x) patches x planes for one workgroup per CU
-inline bool march_level(const Dims& d) {
+// (dilation 2 already at 32^3: the tiled kernel runs it on eight 16^3 parity sub-lattices, where its tiles are mostly halo --
+// measured on 4 x 32^3, 64 -> 64 channels: forward 0.043 vs 0.057 ms, data gradient 0.039 vs 0.059 ms; dilation 1 at that size
+// stays on the tiled kernel, 0.036 vs 0.041 ms)
+inline bool march_level(const Dims& d, int dil) {
   static const long long minvox = [] { const char* e = getenv("SEUNET_MARCH_MINVOX"); return e ? atoll(e) : 48LL * 48 * 48; }();
-  return d.W >= 32 && d.vox() >= minvox;
+  static const bool no_coarse = getenv("SEUNET_MARCH_NO_COARSE") != nullptr;   // (diagnostic switch for A/B timing)
+  return d.W >= 32 && (d.vox() >= minvox || (!no_coarse && dil == 2 && d.vox() >= 32LL * 32 * 32));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -212,7 +216,7 @@ struct Plan {
       r.stream_d = stream_ok && r.need_dgrad && conv_stream_supported(d.dtype, 27, o.dil, r.cout, C[o.src[0]]);
       // 32 / 64-input-channel 3x3x3 layers of the levels that fill the chip with 32-voxel rows run on the marching kernel
       // (one workgroup per CU, weights in registers): dc5, dc4, ec4..ec6 and the data gradients of those and of dc3
-      if (use_march && o.kind == OP_GATED && d.conv_impl != SEUNET_CONV_NAIVE && !r.stream_f && march_level(dims[lv])) {
+      if (use_march && o.kind == OP_GATED && d.conv_impl != SEUNET_CONV_NAIVE && !r.stream_f && march_level(dims[lv], o.dil)) {
         SrcList sl{}; DstList dl{};
         sl.n = o.nsrc;
         for (int k = 0; k < o.nsrc; ++k) sl.C[k] = C[o.src[k]];

@@ -20,6 +20,7 @@
 //               into the PyTorch (Cout,Cin,3,3,3) layout
 #include "seunet_common.h"
 #include <utility>
+#include <cstdlib>
 #include <type_traits>
 
 namespace seunet {
@@ -418,7 +419,8 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int taps, int cin
 
 // persistent workgroups per (ci, co) combo == slabs the reduce kernel has to sum; ~2 resident workgroups per CU in total
 static inline int wgrad_groups(int taps, int combos, int total_tiles) {
-  int g = 512 / combos;   // two resident workgroups per CU
+  static const int per_chip = [] { const char* e = getenv("SEUNET_WGRAD_WGS"); return e ? atoi(e) : 512; }();   // (diagnostic)
+  int g = per_chip / combos;   // two resident workgroups per CU
   if (g < 16) g = 16;
   if (g > 512) g = 512;
   if (g > total_tiles) g = total_tiles;

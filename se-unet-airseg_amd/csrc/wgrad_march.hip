@@ -393,9 +393,15 @@ static bool wgrad_march_cfg(int dtype, int taps, int dil, const SrcList& x, int 
   if (dtype_size(dtype) != 2 || taps != 27 || (dil != 1 && dil != 2)) return false;
   if (x.n < 1 || x.n > 2 || (x.n == 2 && x.C[0] != x.C[1])) return false;
   if (cin_logical != x.total() || cin_logical % 32 || cout % 32 || x.C[0] % 8) return false;
-  if (size_gate) {   // the fine levels only: below, a march is too short for its prologue and the patches too few for the chip
+  if (size_gate) {
+    // where it beats the tiled kernel (isolated launches, 4 samples): the fine levels (rows of >= 32 voxels, >= 48^3); every
+    // dilation-2 layer down to 16^3 (the tiled kernel works on parity sub-lattices there: 32^3 64 -> 64 0.057 vs 0.080 ms, 16^3
+    // 128 -> 128 0.058 vs 0.075 ms); 256-channel inputs (dc1: 0.118 vs 0.134 ms).  Dilation 1 with <= 128 input channels on the
+    // coarse levels is a tie and stays where it was.
     static const bool off = std::getenv("SEUNET_NO_WGRAD_MARCH") != nullptr;
-    if (off || d.W < 32 || (long long)d.D * d.H * d.W < 48LL * 48 * 48) return false;
+    const bool fine = d.W >= 32 && (long long)d.D * d.H * d.W >= 48LL * 48 * 48;
+    static const bool no_coarse = std::getenv("SEUNET_MARCH_NO_COARSE") != nullptr;   // (diagnostic switch for A/B timing)
+    if (off || !(fine || (!no_coarse && (dil == 2 || cin_logical >= 256)))) return false;
   }
   if (cin_logical % 64 == 0) c = {4, 2};
   else if (cout % 64 == 0) c = {2, 4};
