@@ -35,8 +35,9 @@ extern "C" {
 #endif
 #define SEUNET_CONV_MFMA 0   /* implicit-GEMM matrix-core kernels (default)                  */
 #define SEUNET_CONV_NAIVE 1  /* one-thread-per-output HIP kernels (device-side cross-check)  */
-#define SEUNET_CONV_MARCH 2  /* seunet_conv3d_wgrad only: force the marching weight-gradient kernel (SEUNET_CONV_MFMA picks it
-                                by itself for the wide 16-bit layers of large volumes); error when the layer is not served */
+#define SEUNET_CONV_MARCH 2  /* seunet_conv3d_wgrad only: force the marching weight-gradient kernel (taps 27) / the whole-GEMM
+                                1x1x1 kernel (taps 1); SEUNET_CONV_MFMA picks them by itself for the layers and sizes they
+                                win on; error when the layer is not served */
 #define SEUNET_CONV_TILED 3  /* seunet_conv3d_wgrad only: the tiled weight-gradient kernel whatever the size                */
 
 typedef void* seunet_stream_t; /* a hipStream_t */

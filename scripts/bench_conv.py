@@ -14,7 +14,8 @@ CASES = [("dc5", [32, 32], 32, 1, 128), ("dc3", [64, 64], 64, 1, 64), ("ec3", [1
          ("ec2", [8], 16, 1, 128), ("ec6", [32], 64, 2, 64), ("dc4", [64], 32, 1, 64), ("ec4", [32], 32, 1, 64), ("ec5", [32], 32, 2, 64),
          ("ec8", [64], 64, 2, 32), ("dc2", [64], 64, 1, 32), ("dc1", [128, 128], 64, 1, 32), ("ec11", [128], 128, 2, 16),
          # 1x1x1 layers (name ends in "_1"): the x33 / ec33 shortcut convolutions
-         ("x33_1", [8], 32, 1, 128), ("ec33_1", [32], 32, 1, 128), ("ec63_1", [64], 64, 1, 64)]
+         ("x33_1", [8], 32, 1, 128), ("ec33_1", [32], 32, 1, 128), ("ec63_1", [64, 32, 32], 64, 1, 64), ("ec93_1", [64, 64, 64], 128, 1, 32),
+         ("dc42_1", [32, 32], 32, 1, 64), ("dc22_1", [64, 64], 64, 1, 32)]
 dt = torch.bfloat16
 for name, split, cout, dil, size in CASES:
     if only and only != name:
@@ -114,6 +115,11 @@ for name, split, cout, dil, size in CASES:
         err = max(float((a.float() - b.float()).abs().max()) / float(b.float().abs().max()) for a, b in zip(gs_m, gs))
         ms = timeit(mdgrad)
         res.append("MARCH dgrad %.3f ms %.0f TF/s (rel diff %.1e)" % (ms, flops / ms / 1e9, err))
+    if TAPS == 1 and "wgrad" in which and all(c in (32, 64) for c in split) and cin in (64, 128, 192):
+        wgrad(3); ref_dw = dw.clone(); wgrad(2); torch.cuda.synchronize()
+        err = float((dw - ref_dw).abs().max()) / float(ref_dw.abs().max())
+        ms = timeit(lambda: wgrad(2))
+        res.append("1x1 wgrad %.3f ms (rel diff %.1e)" % (ms, err))
     if TAPS == 27 and cin % 32 == 0 and cout % 32 == 0 and len(set(split)) == 1 and len(split) <= 2 and "wgrad" in which:
         wgrad(3); ref_dw = dw.clone(); wgrad(2); torch.cuda.synchronize()
         err = float((dw - ref_dw).abs().max()) / float(ref_dw.abs().max())

@@ -133,7 +133,8 @@ int seunet_conv3d_wgrad(int dtype, int impl, int taps, int dilation, int nsrc, c
   if (impl == SEUNET_CONV_NAIVE) return launch_wgrad_naive(dtype, taps, dilation, sl, cin, dy, cout, dw, D(dims), S(s));
   SEUNET_CHECK(workspace, "conv3d_wgrad: null workspace");
   if (impl == SEUNET_CONV_MARCH)
-    return launch_wgrad_march(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s));
+    return taps == 1 ? launch_wgrad_1x1(dtype, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s))
+                     : launch_wgrad_march(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s));
   return launch_wgrad(dtype, taps, dilation, sl, cin, dy, cout, dw, workspace, workspace_bytes, D(dims), S(s), impl != SEUNET_CONV_TILED);
 }
 

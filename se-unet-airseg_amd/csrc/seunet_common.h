@@ -259,6 +259,10 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
 bool wgrad_march_supported(int dtype, int taps, int dil, const SrcList& x, int cin_logical, int cout, Dims d);
 int launch_wgrad_march(int dtype, int taps, int dil, const SrcList& x, int cin_logical, const void* dy, int cout,
                        float* dw, void* workspace, size_t ws_bytes, Dims d, hipStream_t s);
+// 1x1x1 weight gradient of the aggregation convolutions (wgrad_1x1.hip)
+bool wgrad_1x1_supported(int dtype, const SrcList& x, int cin_logical, int cout, Dims d);
+int launch_wgrad_1x1(int dtype, const SrcList& x, int cin_logical, const void* dy, int cout, float* dw, void* workspace,
+                     size_t ws_bytes, Dims d, hipStream_t s);
 int launch_wgrad_naive(int dtype, int taps, int dil, const SrcList& x, int cin_logical,
                        const void* dy, int cout, float* dw_torch, Dims d, hipStream_t s);
 

@@ -432,7 +432,12 @@ static inline int wgrad_groups(int taps, int combos, int total_tiles) {
 size_t wgrad_workspace_bytes(int taps, int cin, int cout) {
   const int combos = cdiv(cin, 32) * cdiv(cout, 32);
   const int g = 512 / combos < 16 ? 16 : (512 / combos > 512 ? 512 : 512 / combos);
-  return 256 + (size_t)combos * g * taps * 1024 * sizeof(float);   // 256 zero bytes + slabs
+  size_t bytes = 256 + (size_t)combos * g * taps * 1024 * sizeof(float);   // 256 zero bytes + slabs
+  if (taps == 1) {   // the whole-GEMM 1x1x1 kernel (wgrad_1x1.hip): 256 workgroups x all 16 x 16 pairs
+    const size_t b1 = 256 + (size_t)256 * (size_t)(cdiv(cin, 64) * 4) * (size_t)cdiv(cout, 16) * 256 * sizeof(float);
+    if (b1 > bytes) bytes = b1;
+  }
+  return bytes;
 }
 
 template <typename T, int TAPS, int DIL, int NW>
@@ -458,6 +463,8 @@ int launch_wgrad(int dtype, int taps, int dil, const SrcList& x, int cin_logical
   SEUNET_CHECK(x.n >= 1 && x.n <= 3, "wgrad: 1..3 sources");
   SEUNET_CHECK(cout % 8 == 0 && cin_logical >= 1 && cin_logical <= x.total(), "wgrad: bad channel counts");
   SEUNET_CHECK(ws_bytes >= wgrad_workspace_bytes(taps, cin_logical, cout), "wgrad: workspace too small");
+  if (allow_march && taps == 1 && wgrad_1x1_supported(dtype, x, cin_logical, cout, d))   // aggregation convs: wgrad_1x1.hip
+    return launch_wgrad_1x1(dtype, x, cin_logical, dy, cout, dw, workspace, ws_bytes, d, s);
   if (allow_march && wgrad_march_supported(dtype, taps, dil, x, cin_logical, cout, d))     // wide layers of the fine levels: wgrad_march.hip
     return launch_wgrad_march(dtype, taps, dil, x, cin_logical, dy, cout, dw, workspace, ws_bytes, d, s);
   WgArgs a{};

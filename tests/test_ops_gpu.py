@@ -192,6 +192,31 @@ def test_conv_weight_gradient_march(S, dtype, case):
     assert_close(dw, S.conv3d_wgrad(srcs, dyc, cin, cout, 27, dil, S._lib.CONV_TILED).cpu(), "fp32", "march vs tiled")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [([64, 32, 32], 64, (2, 5, 6, 40)),      # ec63: 2 input blocks per wave, 128-voxel chunks, ragged tail
+                                  ([64, 64, 64], 128, (1, 9, 8, 24)),     # ec93: 3 blocks per wave, 64-voxel chunks
+                                  ([32, 32], 32, (2, 3, 5, 7)),           # dc42: 210 voxels = one full chunk + a partial one
+                                  ([64, 64], 64, (1, 16, 16, 16))])       # dc22
+def test_conv_weight_gradient_1x1(S, dtype, case):
+    """csrc/wgrad_1x1.hip (forced: the dispatcher only picks it for >= 16384 voxels) against F.conv3d's weight gradient, and
+    against the tiled kernel."""
+    split, cout, (n, d, h, w) = case
+    cin = sum(split)
+    x = rnd(dtype, gen(n, cin, d, h, w, seed=14))
+    dy = rnd(dtype, gen(n, cout, d, h, w, seed=15))
+    wt = torch.zeros(cout, cin, 1, 1, 1, requires_grad=True)
+    F.conv3d(x, wt).backward(dy)
+    srcs, o = [], 0
+    for c in split:
+        srcs.append(S.to_cl(x[:, o:o + c].cuda(), dtype))
+        o += c
+    dyc = S.to_cl(dy.cuda(), dtype)
+    dw = S.conv3d_wgrad(srcs, dyc, cin, cout, 1, 1, S._lib.CONV_MARCH)
+    assert_close(dw, wt.grad, "fp32", "wgrad 1x1")
+    assert torch.equal(dw, S.conv3d_wgrad(srcs, dyc, cin, cout, 1, 1, S._lib.CONV_MARCH))
+    assert_close(dw, S.conv3d_wgrad(srcs, dyc, cin, cout, 1, 1, S._lib.CONV_TILED).cpu(), "fp32", "1x1 vs tiled")
+
+
 def test_conv_weight_gradient_march_refuses_unserved_layers(S):
     x = S.to_cl(torch.zeros(1, 16, 4, 4, 32).cuda(), "bf16")
     dy = S.to_cl(torch.zeros(1, 32, 4, 4, 32).cuda(), "bf16")
