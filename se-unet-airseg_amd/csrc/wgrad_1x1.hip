@@ -266,7 +266,8 @@ static bool wgrad_1x1_cfg(int dtype, const SrcList& x, int cin_logical, int cout
     // dc22 (8 combos but 131 k voxels: 0.033 vs 0.023 ms, four chunks per workgroup do not amortise the pipeline fill)
     const int combos = cdiv(cin_logical, 32) * cdiv(cout, 32);
     const long long nv = (long long)d.N * d.vox();
-    if (off || !(combos >= 16 || (combos >= 8 && nv >= 500000))) return false;
+    static const bool all = std::getenv("SEUNET_WGRAD_1X1_ALL") != nullptr;   // (diagnostic: every layer the kernel serves)
+    if (off || !(all || combos >= 16 || (combos >= 8 && nv >= 500000))) return false;
   }
   return true;
 }
