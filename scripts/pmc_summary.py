@@ -54,7 +54,9 @@ for key, (f, w) in table.items():
 # forward <.., 2, 2, 4, 1, 0> shares instantiation and grid with dc4's forward and is the LAST such launch of every forward pass.
 def march_is(name, sig):
     n = name.replace(" ", "")
-    return "conv_march_kernel" in n and (",".join(map(str, sig)) + ">" in n or "".join("Li%dE" % v for v in sig) in n)
+    # (rocprofv3 prints some instantiations demangled with the first integer argument swallowed: "<bool _Accum, int, E, 4, 8, 1, 1>")
+    return "conv_march_kernel" in n and (",".join(map(str, sig)) + ">" in n or "".join("Li%dE" % v for v in sig) in n or
+                                         ("E," + ",".join(map(str, sig[1:])) + ">" in n and len(sig) == 5))
 def last_of_each_step(v):
     v = sorted(v)
     per = max(len(v) // STEPS, 1)
