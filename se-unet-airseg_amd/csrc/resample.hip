@@ -956,13 +956,32 @@ __global__ void up_transpose_axis_kernel(const float* __restrict__ in, float* __
 // sum(g_pred).  The interpolation weights depend on the x index only: each block tabulates them once in LDS (range start
 // + up to HB_K weights per output and level) and then streams HB_ROWS x-rows, one wave per row.  Same weights and the same
 // summation order as up_transpose_axis_kernel (bitwise identical results).
-constexpr int HB_ROWS = 32, HB_K = 24;
+constexpr int HB_ROWS = 32, HB_K = 24, HB_PAD = 24, HB_KA = 8, HB_KB = 24;
 __global__ void __launch_bounds__(256)
 head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, float* __restrict__ t1b, float* __restrict__ t1c,
                         int nl, int W, long long rows, double* __restrict__ bias_part) {
-  extern __shared__ float hsm[];                        // [4][W] row buffers, then per output the table: lo, n, HB_K weights
-  float* tab = hsm + 4 * W;
+  extern __shared__ float hsm[];                        // [4][W + HB_PAD] row buffers (pad = zeros), then per output the table: lo, n, HB_K weights
+  const int RW = W + HB_PAD;
+  float* tab = hsm + 4 * RW;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long row0 = (long long)blockIdx.x * HB_ROWS;
+  // rows of up to 256 values: ALL HB_ROWS / 4 rows of this wave are requested up front (registers), before the weight
+  // table is built: with one row in flight
+  // per wave the kernel moved 0.9 TB/s (bytes in flight x waves / HBM latency), not the table look-ups' fault
+  constexpr int RPW = HB_ROWS / 4;
+  const bool pf = W <= 256;
+  float pre[RPW][4];
+  if (pf) {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const long long row = row0 + wv + 4 * j;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = lane + 64 * k;
+        pre[j][k] = (row < rows && x < W) ? g[row * W + x] : 0.f;
+      }
+    }
+  }
   float* const outs[3] = {t1a, t1b, t1c};
   // table: outputs of level l occupy entries [ebase_l, ebase_l + W >> l)
   int ebase[4] = {0, 0, W >> 1, (W >> 1) + (W >> 2)};
@@ -986,39 +1005,63 @@ head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, fl
     t[0] = __int_as_float(first);
     t[1] = __int_as_float(cnt < HB_K ? cnt : HB_K);
   }
+  for (int i = threadIdx.x; i < 4 * HB_PAD; i += 256) hsm[(i / HB_PAD) * RW + W + i % HB_PAD] = 0.f;
   __syncthreads();
-  double sum = 0.0;
-  const long long row0 = (long long)blockIdx.x * HB_ROWS;
-  // rows of up to 256 values: the next row of this wave is fetched (registers) before the current one is processed -- the
-  // loop is otherwise a chain of dependent global load -> LDS -> compute per row
-  const bool pf = W <= 256;
-  float nxt[4] = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](long long row) __attribute__((always_inline)) {
+  // Fast path (<= 128 entries, i.e. W <= 146): a lane owns the same two entries (lane, lane + 64) in every row, so their taps
+  // live in REGISTERS for the whole block -- the per-row work is then 30-odd LDS reads and FMAs instead of table look-ups.
+  // (Measured by elimination at 4 x 128^3: row loads + LDS writes + bias sums 12.8 us, weight table 5 us, taps + stores 21 us;
+  // the taps are unbalanced -- 16 lanes carry the ~20-tap level-3 entries -- which is what is left to fix.)  Taps beyond an entry's count carry
+  // weight 0 and read the zero pad behind the row; skipping a zero weight and adding 0 * v give the same bits.
+  const int e0 = lane, e1 = lane + 64;
+  float wa[HB_KA], wb[HB_KB];
+  int fa = 0, fb = 0, ca = 0, cb = 0;
+  {
+    if (e0 < nent) { const float* t = tab + e0 * (HB_K + 2); fa = __float_as_int(t[0]); ca = __float_as_int(t[1]); }
+    if (e1 < nent) { const float* t = tab + e1 * (HB_K + 2); fb = __float_as_int(t[0]); cb = __float_as_int(t[1]); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int x = lane + 64 * k;
-      nxt[k] = (row < rows && x < W) ? g[row * W + x] : 0.f;
-    }
-  };
-  if (pf) fetch(row0 + wv);
-  for (int rr = wv; rr < HB_ROWS; rr += 4) {
+    for (int k = 0; k < HB_KA; ++k) wa[k] = (e0 < nent && k < ca) ? tab[e0 * (HB_K + 2) + 2 + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < HB_KB; ++k) wb[k] = (e1 < nent && k < cb) ? tab[e1 * (HB_K + 2) + 2 + k] : 0.f;
+  }
+  const bool fast = nent <= 128 && __all(ca <= HB_KA && cb <= HB_KB && fa + HB_KA <= RW && fb + HB_KB <= RW);   // (wave-uniform)
+  int ka = 0, kb = 0;                                    // taps to walk: the wave's maxima, rounded up to 4
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { ca = max(ca, __shfl_xor(ca, off, 64)); cb = max(cb, __shfl_xor(cb, off, 64)); }
+  ka = (ca + 3) & ~3; kb = (cb + 3) & ~3;
+  const int la = e0 < ebase[2] ? 1 : (e0 < ebase[3] ? 2 : 3), lb = e1 < ebase[2] ? 1 : (e1 < ebase[3] ? 2 : 3);
+  float* const outa = e0 < nent ? (la == 1 ? t1a : (la == 2 ? t1b : t1c)) : nullptr;
+  float* const outb = e1 < nent ? (lb == 1 ? t1a : (lb == 2 ? t1b : t1c)) : nullptr;
+  const int cola = e0 - ebase[la], colb = e1 - ebase[lb], wla = W >> la, wlb = W >> lb;
+  double sum = 0.0;
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int rr = wv + 4 * j;
     const long long row = row0 + rr;
     if (row >= rows) break;                              // (wave-uniform)
-    float* rb = hsm + wv * W;
+    float* rb = hsm + wv * RW;
     if (pf) {
-      float cur[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
-      if (rr + 4 < HB_ROWS) fetch(row + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int x = lane + 64 * k;
-        if (x < W) { rb[x] = cur[k]; sum += (double)cur[k]; }
+        if (x < W) { rb[x] = pre[j][k]; sum += (double)pre[j][k]; }
       }
     } else {
       for (int x = lane; x < W; x += 64) { const float v = g[row * W + x]; rb[x] = v; sum += (double)v; }
     }
     __builtin_amdgcn_wave_barrier();                     // LDS operations of one wave complete in order
+    if (fast) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < HB_KA; ++k)
+        if (k < ka) a0 += wa[k] * rb[fa + k];
+#pragma unroll
+      for (int k = 0; k < HB_KB; ++k)
+        if (k < kb) a1 += wb[k] * rb[fb + k];
+      if (outa) outa[row * wla + cola] = a0;
+      if (outb) outb[row * wlb + colb] = a1;
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     for (int e = lane; e < nent; e += 64) {
       const int l = e < ebase[2] ? 1 : (e < ebase[3] ? 2 : 3);
       float* out = outs[l - 1];
@@ -1334,7 +1377,7 @@ int launch_head_bwd(const float* g_pred, float* const* g_levels, int nlevels, fl
   const int nblk = (int)((rows + HB_ROWS - 1) / HB_ROWS);
   SEUNET_CHECK(d0.W <= 1024, "head_bwd: W=%d too large", d0.W);
   SEUNET_CHECK(V / 2 < (1ll << 31), "head_bwd: %lld voxels per call exceed the 32-bit index range of the axis passes", V);
-  const size_t lds = ((size_t)4 * d0.W + (size_t)(d0.W - (d0.W >> 3)) * (HB_K + 2)) * sizeof(float);
+  const size_t lds = ((size_t)4 * (d0.W + HB_PAD) + (size_t)(d0.W - (d0.W >> 3)) * (HB_K + 2)) * sizeof(float);
   head_bwd_x_multi_kernel<<<nblk, 256, lds, s>>>(g_pred, t1[1], t1[2], t1[3], nlevels, d0.W, rows, g_bias ? part : nullptr);
   // y-pass of every level in one launch, then z-pass of every level in one launch
   AxisJobs jy{}, jz{};
