@@ -72,7 +72,14 @@ class GradSync:
     def decoder_event(self):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return None
-        return torch.cuda.Event()
+        # A torch event has no HIP handle until its first record(): ``ev.cuda_event`` would be 0, the library would record nothing
+        # and ``wait_event`` on a never-recorded event is a no-op -- the side stream would reduce the decoder's gradients before
+        # they are written.  Record once here (the library's record at the decoder boundary supersedes it).
+        ev = torch.cuda.Event()
+        ev.record()
+        if not ev.cuda_event:
+            raise RuntimeError("GradSync: could not create the decoder-boundary event")
+        return ev
 
     def exchange(self, flat: torch.Tensor, split: int, ev) -> None:
         if ev is None:

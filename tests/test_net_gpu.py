@@ -660,8 +660,13 @@ def _dp_worker(rank, world, port, backend, q, overlap=False):
         x, lab = b["image"][rank:rank + 1].to(dev), b["label"][rank:rank + 1].to(dev)
         if overlap:      # the exchange runs inside backward(): decoder bucket on a side stream, the rest after the backward
             m.grad_sync = _ddp.GradSync(timing=True)
+            assert m.grad_sync.decoder_event().cuda_event != 0    # (a torch event has no handle before its first record)
         e, d = m(x)
         loss = _A.fused_stage_loss(1, e, d, lab, group=True)      # global-batch ratio: sums all-reduced first
+        if overlap:
+            # put the launch stream ~100 ms behind the host: a side stream that does NOT wait for the decoder-boundary event then
+            # reduces gradient memory the backward pass has not written yet, and the comparison below fails
+            _t.cuda._sleep(200_000_000)
         loss.backward()
         grads = [p.grad for p in m.parameters() if p.grad is not None]
         zero_copy = _ddp._flat_view(grads) is not None            # real backward -> one contiguous bucket
