@@ -321,6 +321,9 @@ def main():
     value = voxels_step * args.steps / dt
     ms_step = 1e3 * dt / args.steps
     ar_ms = model.grad_sync.elapsed_ms() if overlap else [a.elapsed_time(b) for a, b in ar_events]
+    if world > 1 and len(ar_ms) != args.steps:
+        # a data-parallel step without its gradient exchange is a different (and wrong) workload: never report it
+        raise SystemExit(f"bench.py: world_size {world} but {len(ar_ms)} gradient exchanges were timed in {args.steps} steps")
     if rank == 0:
         print("per-step ms: " + " ".join(f"{v:.2f}" for v in per_step_ms), file=sys.stderr)
 

@@ -147,24 +147,27 @@ int seunet_cat_epilogue_bwd(int dtype, const void* g_out, const void* raw, const
  * SE_UNet.py:112,118,124,187,196,205).  That conv's output is never materialised: every pass recomputes
  * raw2[c] = w2[c][0]*x0 + w2[c][1]*x1 from x_in, the packed 8-channel input [N][D][H][W][8] of the level (16 B per voxel
  * instead of 2*c); its InstanceNorm statistics follow from the input's second moments (seunet_xbranch_moments ->
- * seunet_xbranch_stats, exact in f64); and pass B of the backward accumulates the conv's weight gradient
- * dW2[c][i] = sum draw2[c]*x[i] itself (one record per block in xw_partial: seunet_cat_xgrad_records(dims) * c * 2
- * floats), which seunet_cat_xgrad_reduce sums into dw (c, in_channel, 1, 1, 1).  w2: (c, in_channel) f32. */
+ * seunet_xbranch_stats, exact in f64; moments_out, optional, keeps the per-sample means of x0, x1, x0^2, x0 x1, x1^2 for
+ * the backward pass).  The conv's weight gradient dW2[c][i] = sum_v draw2[c] * x[i] is what is left of O(1) terms that cancel
+ * to ~1e-5 of their size at 128^3, so it is not accumulated from the f32 draw2: pass A of the backward also sums
+ * dxhat2[c] * x[i] (one f64 record per block in xw_partial: n * seunet_epilogue_slots(dims) * c * 2 doubles) and
+ * seunet_cat_xgrad_finalize forms dw (c, in_channel, 1, 1, 1) in f64 from those sums, stat_partial2 and the moments
+ * (train.py:602 loss.backward() through SE_UNet.py:112,118,124).  w2: (c, in_channel) f32. */
 int seunet_xbranch_moment_slots(seunet_dims dims);
 int seunet_xbranch_moments(int dtype, const void* x_in, double* partial /* [n][slots][5] */, seunet_dims dims, seunet_stream_t s);
 int seunet_xbranch_stats(const double* partial, int slots, const float* w2, int c, int in_channel, int n, long long count,
-                         float eps, float* mean2, float* rstd2, seunet_stream_t s);
+                         float eps, float* mean2, float* rstd2, double* moments_out /* [n][5] or NULL */, seunet_stream_t s);
 int seunet_cat_epilogue_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in,
                               const float* w2, int in_channel, const float* mean2, const float* rstd2, int c, float slope,
                               void* out, seunet_dims dims, seunet_stream_t s);
-/* pass A (m1 == NULL): f64 partials of both branches; pass B: dx (may alias g_out) + xw_partial */
+/* pass A (m1 == NULL): f64 partials of both branches (+ xw_partial when given); pass B: dx (may alias g_out) */
 int seunet_cat_epilogue_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
                               const void* x_in, const float* w2, int in_channel, const float* mean2, const float* rstd2,
                               int c, float slope, const float* m1, const float* m2, const float* m1b, const float* m2b,
-                              void* dx, double* stat_partial, double* stat_partial2, float* xw_partial, seunet_dims dims,
+                              void* dx, double* stat_partial, double* stat_partial2, double* xw_partial, seunet_dims dims,
                               seunet_stream_t s);
-int seunet_cat_xgrad_records(seunet_dims dims);
-int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_channel, float* dw, seunet_stream_t s);
+int seunet_cat_xgrad_finalize(const double* xw_partial, const double* stat_partial2, int slots, const double* moments,
+                              const float* w2, int c, int in_channel, int n, float eps, float* dw, seunet_stream_t s);
 
 /* ---- nn.MaxPool3d(2,2) SE_UNet.py:131-133 ; nn.Upsample(x2 trilinear align_corners) :136-138 ---------- */
 int seunet_maxpool_fwd(int dtype, const void* in, int c, void* out, seunet_dims in_dims, seunet_stream_t s);

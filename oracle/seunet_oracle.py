@@ -348,10 +348,12 @@ def window_starts(dim: int, cube: int = 128, step: int = 64) -> List[int]:
     return out
 
 
-def sliding_window_predict(model: nn.Module, x: torch.Tensor, cube: int = 128, step: int = 64
+def sliding_window_predict(model: nn.Module, x: torch.Tensor, cube: int = 128, step: int = 64, sigmoid: bool = True
                            ) -> np.ndarray:
     """prediction.py:78-109: per window ``sigmoid(pred1)`` accumulated into float64
-    host buffers with an overlap count, then divided.  ``x`` is (1,C,X,Y,Z)."""
+    host buffers with an overlap count, then divided.  ``x`` is (1,C,X,Y,Z).
+    ``sigmoid=False``: save_gradients.py:129-137 / weight_br.py:95-102, the same loop on the RAW
+    logits (``pred += p_numpy``; those scripts run under ``case_net.train()``: the caller sets the mode)."""
     _, _, X, Y, Z = x.shape
     acc = np.zeros((1, 1, X, Y, Z))
     cnt = np.zeros((1, 1, X, Y, Z))
@@ -360,7 +362,7 @@ def sliding_window_predict(model: nn.Module, x: torch.Tensor, cube: int = 128, s
             for yl in window_starts(Y, cube, step):
                 for zl in window_starts(Z, cube, step):
                     _, p = model(x[:, :, xl:xl + cube, yl:yl + cube, zl:zl + cube])
-                    p = torch.sigmoid(p).cpu().numpy()
+                    p = (torch.sigmoid(p) if sigmoid else p).cpu().numpy()
                     acc[:, :, xl:xl + cube, yl:yl + cube, zl:zl + cube] += p
                     cnt[:, :, xl:xl + cube, yl:yl + cube, zl:zl + cube] += 1
     return np.squeeze(acc / cnt)

@@ -209,18 +209,22 @@ class _SEUNetFunction(torch.autograd.Function):
             flat, grads, split = alloc_flat_grads(ctx.plist, ctx.dead, dev, ctx.names)
             garr = _lib.ptr_array(grads)
             parr = _lib.ptr_array(ctx.plist)
-            sync = ctx.grad_sync if (ctx.grad_sync is not None and ctx.loss_scale == 1.0) else None
+            sync = ctx.grad_sync
             ev = sync.decoder_event() if sync is not None else None
             _lib.check(lib.seunet_net_backward_ev(C.byref(ctx.desc), parr, g0.data_ptr(), g1.data_ptr(),
                                                   _lib.ptr(ctx.drop[0]), _lib.ptr(ctx.drop[1]), garr,
                                                   ctx.ws.data_ptr(), ctx.ws_bytes, _lib.stream_ptr(),
                                                   None if ev is None else ev.cuda_event), "net_backward")
             if sync is not None:      # data parallel: decoder bucket on the side stream (already under way), the rest here
+                # (with a loss scale the SCALED buffer is what is summed over the ranks; the finiteness test below then runs on the
+                # global sum: an inf / NaN on any one rank is an inf / NaN in every rank's sum, so all ranks drop the step together)
                 sync.exchange(flat, split, ev)
             if ctx.loss_scale != 1.0:
                 # a scaled activation gradient beyond half precision's range turns into inf / NaN in the flat buffer: such a step
                 # is dropped (zero gradients) and counted on the device, with no host synchronisation -- the caller reads
-                # ``model.overflow_steps`` when it wants to (and lowers ``model.loss_scale`` if it ever becomes non-zero)
+                # ``model.overflow_steps`` when it wants to (and lowers ``model.loss_scale`` if it ever becomes non-zero).
+                # Without ``grad_sync`` (``ddp.allreduce_gradients`` after the backward) the decision is per rank: a rank that
+                # overflowed contributes zeros to the sum; the ranks still apply the same update.
                 ok = torch.isfinite(flat).all()
                 flat.copy_(torch.where(ok, flat * (1.0 / ctx.loss_scale), torch.zeros((), dtype=flat.dtype, device=dev)))
                 if ctx.overflow is not None:

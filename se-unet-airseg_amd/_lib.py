@@ -80,13 +80,12 @@ PROTOTYPES = {
     "seunet_loss_sums": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _vp, _vp, _i, _vp]),
     "seunet_loss_value": (_i, [_vp, _d, _d, _d, _vp, _d, _d, _d, _vp, _vp]),
     "seunet_loss_grad": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
-    "seunet_cat_xgrad_records": (_i, [Dims]),
     "seunet_xbranch_moment_slots": (_i, [Dims]),
     "seunet_xbranch_moments": (_i, [_i, _vp, _vp, Dims, _vp]),
-    "seunet_xbranch_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _ll, _f, _vp, _vp, _vp]),
+    "seunet_xbranch_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _ll, _f, _vp, _vp, _vp, _vp]),
     "seunet_cat_epilogue_fwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, Dims, _vp]),
     "seunet_cat_epilogue_bwd_x": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dims, _vp]),
-    "seunet_cat_xgrad_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "seunet_cat_xgrad_finalize": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "seunet_cc_workspace_bytes": (_sz, [_i, _i, _i]),
     "seunet_largest_component": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "seunet_metric_out_bytes": (_sz, [_i]),

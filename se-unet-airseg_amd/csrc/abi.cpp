@@ -245,16 +245,15 @@ int seunet_loss_grad(const float* pred, int apply_sigmoid, const float* target, 
   return launch_loss_grad(pred, apply_sigmoid, target, weight, skel, n, sums, c_dice, c_gul, c_atr, g_scale, g_scale_dev, g_pred, S(s));
 }
 
-int seunet_cat_xgrad_records(seunet_dims dims) { return cat_xgrad_records(D(dims)); }
 int seunet_xbranch_moment_slots(seunet_dims dims) { return xbranch_moment_slots(D(dims)); }
 int seunet_xbranch_moments(int dtype, const void* x_in, double* partial, seunet_dims dims, seunet_stream_t s) {
   SEUNET_CHECK(x_in && partial, "xbranch_moments: null argument");
   return launch_xbranch_moments(dtype, x_in, partial, D(dims), S(s));
 }
 int seunet_xbranch_stats(const double* partial, int slots, const float* w2, int c, int in_channel, int n, long long count,
-                         float eps, float* mean2, float* rstd2, seunet_stream_t s) {
+                         float eps, float* mean2, float* rstd2, double* moments_out, seunet_stream_t s) {
   SEUNET_CHECK(partial && w2 && mean2 && rstd2 && slots >= 1 && c >= 1 && n >= 1 && count >= 1, "xbranch_stats: bad argument");
-  return launch_xbranch_stats(partial, slots, w2, c, in_channel, n, count, eps, mean2, rstd2, S(s));
+  return launch_xbranch_stats(partial, slots, w2, c, in_channel, n, count, eps, mean2, rstd2, moments_out, S(s));
 }
 int seunet_cat_epilogue_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in,
                               const float* w2, int in_channel, const float* mean2, const float* rstd2, int c, float slope,
@@ -265,15 +264,16 @@ int seunet_cat_epilogue_fwd_x(int dtype, const void* raw, const float* mean, con
 int seunet_cat_epilogue_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd,
                               const void* x_in, const float* w2, int in_channel, const float* mean2, const float* rstd2,
                               int c, float slope, const float* m1, const float* m2, const float* m1b, const float* m2b,
-                              void* dx, double* stat_partial, double* stat_partial2, float* xw_partial, seunet_dims dims,
+                              void* dx, double* stat_partial, double* stat_partial2, double* xw_partial, seunet_dims dims,
                               seunet_stream_t s) {
   SEUNET_CHECK(g_out && raw && mean && rstd && x_in && w2 && mean2 && rstd2, "cat_epilogue_bwd_x: null argument");
   return launch_cat_bwd_x(dtype, g_out, raw, mean, rstd, x_in, w2, in_channel, mean2, rstd2, c, slope, m1, m2, m1b, m2b, dx,
                           stat_partial, stat_partial2, xw_partial, D(dims), S(s));
 }
-int seunet_cat_xgrad_reduce(const float* xw_partial, int records, int c, int in_channel, float* dw, seunet_stream_t s) {
-  SEUNET_CHECK(xw_partial && dw && records >= 1 && c >= 8, "cat_xgrad_reduce: bad argument");
-  return launch_cat_xgrad_reduce(xw_partial, records, c, in_channel, dw, S(s));
+int seunet_cat_xgrad_finalize(const double* xw_partial, const double* stat_partial2, int slots, const double* moments, const float* w2,
+                              int c, int in_channel, int n, float eps, float* dw, seunet_stream_t s) {
+  SEUNET_CHECK(xw_partial && stat_partial2 && moments && w2 && dw && slots >= 1 && c >= 8 && n >= 1, "cat_xgrad_finalize: bad argument");
+  return launch_cat_xgrad_finalize(xw_partial, stat_partial2, slots, moments, w2, c, in_channel, n, eps, dw, S(s));
 }
 
 size_t seunet_cc_workspace_bytes(int h, int w, int z) {

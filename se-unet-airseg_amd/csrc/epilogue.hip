@@ -468,7 +468,8 @@ input_moments_kernel(const T* __restrict__ xin, double* __restrict__ partial, lo
 // one 256-thread block per sample: fixed-order sum of the moment partials, then mean / rstd of every output channel
 __global__ void __launch_bounds__(256)
 xbranch_stats_kernel(const double* __restrict__ partial, int slots, const float* __restrict__ w2, int C, int ic,
-                     double inv_count, float eps, float* __restrict__ mean2, float* __restrict__ rstd2) {
+                     double inv_count, float eps, float* __restrict__ mean2, float* __restrict__ rstd2,
+                     double* __restrict__ moments_out) {
   const int n = blockIdx.x;
   __shared__ double red[4][5], tot[5];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -486,6 +487,8 @@ xbranch_stats_kernel(const double* __restrict__ partial, int slots, const float*
   __syncthreads();
   if (threadIdx.x < 5) tot[threadIdx.x] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * inv_count;
   __syncthreads();
+  // (kept for the backward pass: the x-branch weight gradient is formed from these and two sums per channel, xw_finalize_kernel)
+  if (moments_out != nullptr && threadIdx.x < 5) moments_out[n * 5 + threadIdx.x] = tot[threadIdx.x];
   const double m0 = tot[0], m1 = tot[1];
   const double c00 = tot[2] - m0 * m0, c01 = tot[3] - m0 * m1, c11 = tot[4] - m1 * m1;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -595,9 +598,13 @@ __device__ __forceinline__ void pool_locate(const PoolRef& pr, unsigned v, unsig
 
 // APPLY = false: per-(n,c) f64 sums of dxhat, dxhat*xhat for one or two branches (nothing stored)
 // APPLY = true : draw = rstd * (dxhat - m1 - xhat * m2) for each branch (dxhat_out may alias g_out)
-// XW (pass B of a two-branch block whose second branch is a 1x1x1 conv of the <= 2-channel network input, the x33 / x63 /
-//     x93 detail-injection convs): instead of storing draw2 for a separate weight-gradient launch, accumulate that
-//     gradient here, dW2[c][i] = sum_v draw2[v][c] * x[v][i], into one record per block (summed by xw_reduce_kernel)
+// XW (pass A of a two-branch block whose second branch is a 1x1x1 conv of the <= 2-channel network input, the x33 / x63 /
+//     x93 detail-injection convs): that conv's weight gradient dW2[c][i] = sum_v draw2[v][c] * x[v][i] is NOT accumulated
+//     from draw2.  sum_v draw2 = 0 and sum_v draw2 * xhat2 = 0, and xhat2 is itself linear in x, so the sum is what is left of
+//     O(1) terms that cancel to ~1e-5 of their size at 128^3; formed from the f32 draw2 (f32 m1 / m2 / mean / rstd, each a
+//     systematic offset times the voxel count) it was 4.6e-2 off at 1 x 128^3 in fp32 mode -- and so is the fp32 reference.
+//     Instead pass A also sums S_i[c] = sum_v dxhat2[v][c] * x_i[v] (dxhat2 = g * LeakyReLU'; one record per block), and
+//     xw_finalize_kernel forms the gradient in f64 from S_i, sum_v dxhat2 and the input's first / second moments.
 template <typename T, int LPV, bool TWO, bool APPLY, bool XW = false, bool XR = false>
 __global__ void __launch_bounds__(EPI_THREADS)
 cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
@@ -608,7 +615,7 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
                const float* __restrict__ m1bp, const float* __restrict__ m2bp, T* dxhat_out,
                T* dxhat2_out, double* __restrict__ stat_partial,
                double* __restrict__ stat_partial2, long long V,
-               const T* __restrict__ xin = nullptr, float* __restrict__ xw_partial = nullptr,
+               const T* __restrict__ xin = nullptr, double* __restrict__ xw_partial = nullptr,
                const float* __restrict__ w2x = nullptr, int xic = 0, PoolRef pool = PoolRef{}) {
   const int n = blockIdx.y, P = gridDim.x;
   const int cg = threadIdx.x % LPV, vb = threadIdx.x / LPV;
@@ -620,10 +627,11 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
   float mu[8], rs[8], mu2[8], rs2[8], a1[8], a2[8], b1[8], b2[8];
   typedef typename std::conditional<sizeof(T) == 2, float, double>::type SumT;   // (bf16: f32 thread sums, see sse_bwd_kernel)
   SumT s[4][8];
-  float xw[8][2], wa[8], wb[8];
+  SumT xw[8][2];
+  float wa[8], wb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    xw[j][0] = xw[j][1] = 0.f;
+    xw[j][0] = xw[j][1] = 0.0;
     wa[j] = XR ? w2x[(c0 + j) * xic] : 0.f;
     wb[j] = (XR && xic > 1) ? w2x[(c0 + j) * xic + 1] : 0.f;
   }
@@ -690,8 +698,8 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
         if (APPLY) d2[j] = rs2[j] * (d2[j] - b1[j] - xh * b2[j]);
         else { s[2][j] += (SumT)d2[j]; s[3][j] += (SumT)d2[j] * (SumT)xh; }
       }
-      if (APPLY && !XW) store8(dxhat2_out + o, d2);
-      if (XW) {
+      if (APPLY && !XR) store8(dxhat2_out + o, d2);
+      if (XW && !APPLY) {
         float xi[8];
         if (XR) {
 #pragma unroll
@@ -700,31 +708,30 @@ cat_bwd_kernel(const T* g_out, const T* __restrict__ raw,
           load8(xin + ((long long)n * V + v) * 8, xi);   // the packed 8-channel input voxel (16 / 32 B, shared by the LPV lanes)
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { xw[j][0] += d2[j] * xi[0]; xw[j][1] += d2[j] * xi[1]; }
+        for (int j = 0; j < 8; ++j) { xw[j][0] += (SumT)d2[j] * (SumT)xi[0]; xw[j][1] += (SumT)d2[j] * (SumT)xi[1]; }
       }
     }
     if (APPLY) store8(dxhat_out + o, d);  // may alias g_out (same element, read before write)
   }
-  if (XW) {   // block record [C][2], fixed-order sums
-    __shared__ float redx[4][16][16];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (APPLY) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (XW) {   // block record [C][2] (f64), fixed-order sums
+    __shared__ double redx[4][16][16];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float r = stride_sum<LPV>(xw[j][i]);
+        const double r = stride_sum_d<LPV>((double)xw[j][i]);
         if (lane < LPV) redx[wave][lane][j * 2 + i] = r;
       }
     __syncthreads();
-    float* rec = xw_partial + ((long long)n * P + blockIdx.x) * (C * 2);
+    double* rec = xw_partial + ((long long)n * P + blockIdx.x) * (C * 2);
     for (int e = threadIdx.x; e < LPV * 16; e += EPI_THREADS) {
       const int gq = e / 16, k = e % 16;
       rec[(gq * 8 + (k >> 1)) * 2 + (k & 1)] = ((redx[0][gq][k] + redx[1][gq][k]) + redx[2][gq][k]) + redx[3][gq][k];
     }
   }
-  if (APPLY) return;
   __shared__ double red[4][16][32];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -840,28 +847,64 @@ int launch_pgrad_reduce(const float* pgrad_partial, int records, int C, float* d
   return 0;
 }
 
-// dW2 (PyTorch layout (C, in_channel, 1, 1, 1)) = f64 fixed-order sum of the XW block records; one BLOCK per (c, i)
-// (one wave per entry left 16 blocks on the chip walking 4096 records each: 28 us per launch)
+// dW2 (PyTorch layout (C, in_channel, 1, 1, 1)) of an x-branch conv, in f64 from sums (cat_bwd_kernel XW).  Per sample, with
+// xc_k = x_k - mean(x_k), Cov = the input's 2 x 2 covariance (per-voxel mean), xhat2 = rs * sum_k w_k xc_k, rs^2 = 1 / (w' Cov w
+// + eps), dxhat2 = g * LeakyReLU'(xhat2) and A_k = sum_v dxhat2 xc_k = S_k - mean(x_k) * sum_v dxhat2:
+//     draw2 = rs * (dxhat2 - mean(dxhat2) - xhat2 * mean(dxhat2 * xhat2))             (InstanceNorm backward)
+//     dW2_i = sum_v draw2 * x_i = rs * (A_i - rs^2 * (sum_k w_k A_k) * (sum_k w_k Cov_ki))
+// (the mean(dxhat2) term drops out against sum_v xc_i = 0).  The cancellation between A_i and its projection on w happens in
+// f64 here; the f32 inputs of the sums (dxhat2 = g or slope * g, x) enter only through products that are exact in f64.
+// One block per output channel; fixed summation order (slots within a sample, then samples): bitwise reproducible.
 __global__ void __launch_bounds__(256)
-xw_reduce_kernel(const float* __restrict__ part, int records, int C, int in_channel, float* __restrict__ dw) {
+xw_finalize_kernel(const double* __restrict__ xw_partial, const double* __restrict__ stat_partial2, int slots, int C, int N,
+                   const double* __restrict__ moments, const float* __restrict__ w2, int ic, double eps, float* __restrict__ dw) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.x;                     // k = c * 2 + i
-  double s = 0.0;
-  for (int r = threadIdx.x; r < records; r += 256) s += (double)part[(long long)r * (C * 2) + k];
+  const int c = blockIdx.x;
+  __shared__ double red[4][3];
+  const double wa = (double)w2[c * ic], wb = ic > 1 ? (double)w2[c * ic + 1] : 0.0;
+  double g0 = 0.0, g1 = 0.0;
+  for (int n = 0; n < N; ++n) {
+    double s[3] = {0.0, 0.0, 0.0};       // S_0, S_1, sum dxhat2
+    for (int r = threadIdx.x; r < slots; r += 256) {
+      const long long rec = (long long)n * slots + r;
+      s[0] += xw_partial[(rec * C + c) * 2 + 0];
+      s[1] += xw_partial[(rec * C + c) * 2 + 1];
+      s[2] += stat_partial2[(rec * C + c) * 2 + 0];
+    }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-  __shared__ double red[4];
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
-  const int c = k >> 1, i = k & 1;
-  if (threadIdx.x == 0 && i < in_channel) dw[c * in_channel + i] = (float)(((red[0] + red[1]) + red[2]) + red[3]);
+    for (int k = 0; k < 3; ++k) {
+      double r = s[k];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+      if (lane == 0) red[wave][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double S0 = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+      const double S1 = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+      const double Sd = ((red[0][2] + red[1][2]) + red[2][2]) + red[3][2];
+      const double* m = moments + n * 5;      // mean x0, mean x1, mean x0^2, mean x0 x1, mean x1^2
+      const double c00 = m[2] - m[0] * m[0], c01 = m[3] - m[0] * m[1], c11 = m[4] - m[1] * m[1];
+      const double A0 = S0 - m[0] * Sd, A1 = S1 - m[1] * Sd;
+      double var = wa * wa * c00 + 2.0 * wa * wb * c01 + wb * wb * c11;
+      if (var < 0.0) var = 0.0;
+      const double rs2 = 1.0 / (var + eps), rs = sqrt(rs2);
+      const double proj = wa * A0 + wb * A1;
+      g0 += rs * (A0 - rs2 * proj * (wa * c00 + wb * c01));
+      g1 += rs * (A1 - rs2 * proj * (wa * c01 + wb * c11));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    dw[c * ic] = (float)g0;
+    if (ic > 1) dw[c * ic + 1] = (float)g1;
+  }
 }
 
-int cat_xgrad_records(Dims d) { return d.N * epi_partials(d) * 4; }
-
-int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_channel, float* dw, hipStream_t s) {
-  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_xgrad_reduce: in_channel %d (1 or 2)", in_channel);
-  xw_reduce_kernel<<<C * 2, 256, 0, s>>>(xw_partial, records, C, in_channel, dw);
+int launch_cat_xgrad_finalize(const double* xw_partial, const double* stat_partial2, int slots, const double* moments, const float* w2,
+                              int C, int in_channel, int N, float eps, float* dw, hipStream_t s) {
+  SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_xgrad_finalize: in_channel %d (1 or 2)", in_channel);
+  xw_finalize_kernel<<<C, 256, 0, s>>>(xw_partial, stat_partial2, slots, C, N, moments, w2, in_channel, (double)eps, dw);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -910,9 +953,9 @@ int launch_xbranch_moments(int dtype, const void* x_in, double* partial, Dims d,
 }
 
 int launch_xbranch_stats(const double* partial, int slots, const float* w2, int C, int in_channel, int N, long long count,
-                         float eps, float* mean2, float* rstd2, hipStream_t s) {
+                         float eps, float* mean2, float* rstd2, double* moments_out, hipStream_t s) {
   SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "xbranch_stats: in_channel %d (1 or 2)", in_channel);
-  xbranch_stats_kernel<<<N, 256, 0, s>>>(partial, slots, w2, C, in_channel, 1.0 / (double)count, eps, mean2, rstd2);
+  xbranch_stats_kernel<<<N, 256, 0, s>>>(partial, slots, w2, C, in_channel, 1.0 / (double)count, eps, mean2, rstd2, moments_out);
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -1017,12 +1060,12 @@ int launch_cat_fwd_x_pool(int dtype, const void* raw, const float* mean, const f
   return 0;
 }
 
-// m1 == nullptr: pass A (f64 sums of both branches); otherwise pass B: writes dx (may alias g_out) and one x-branch
-// weight-gradient record per block into xw_partial (see cat_bwd_kernel XW / XR)
+// m1 == nullptr: pass A (f64 sums of both branches and, if xw_partial is given, one record of the x-branch weight-gradient sums per
+// block, see cat_bwd_kernel XW / XR); otherwise pass B: writes dx (may alias g_out)
 int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,
                      const float* w2, int in_channel, const float* mean2, const float* rstd2, int C, float slope,
                      const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, double* stat_partial,
-                     double* stat_partial2, float* xw_partial, Dims d, hipStream_t s, const unsigned* pool_argmax, const void* pool_g) {
+                     double* stat_partial2, double* xw_partial, Dims d, hipStream_t s, const unsigned* pool_argmax, const void* pool_g) {
   if (int e = check_c(C)) return e;
   SEUNET_CHECK(in_channel >= 1 && in_channel <= 2, "cat_epilogue_bwd_x: in_channel %d (1 or 2)", in_channel);
   PoolRef pr{};
@@ -1036,11 +1079,12 @@ int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float*
   }
   const bool apply = m1 != nullptr;
   if (!apply) SEUNET_CHECK(stat_partial && stat_partial2, "cat_epilogue_bwd_x pass A needs the partial buffers");
-  else SEUNET_CHECK(m2 && m1b && m2b && dx && xw_partial, "cat_epilogue_bwd_x pass B: missing argument");
+  else SEUNET_CHECK(m2 && m1b && m2b && dx, "cat_epilogue_bwd_x pass B: missing argument");
   dim3 grid(epi_partials(d) * (apply ? 4 : 1), d.N);
   SEUNET_LPV_SWITCH(C / 8, {
     SEUNET_DTYPE_SWITCH(dtype, {
-      if (apply) cat_bwd_kernel<T, LPV, true, true, true, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (T*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, xw_partial, w2, in_channel, pr);
+      if (apply) cat_bwd_kernel<T, LPV, true, true, false, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, m1, m2, m1b, m2b, (T*)dx, nullptr, nullptr, nullptr, d.vox(), nullptr, nullptr, w2, in_channel, pr);
+      else if (xw_partial) cat_bwd_kernel<T, LPV, true, false, true, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, xw_partial, w2, in_channel, pr);
       else cat_bwd_kernel<T, LPV, true, false, false, true><<<grid, EPI_THREADS, 0, s>>>((const T*)g_out, (const T*)raw, mean, rstd, (const T*)x_in, mean2, rstd2, C, slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partial, stat_partial2, d.vox(), nullptr, nullptr, w2, in_channel, pr);
     });
   });

@@ -136,7 +136,7 @@ inline bool march_level(const Dims& d, int dil) {
 // workspace plan
 // ---------------------------------------------------------------------------------------------------
 struct OpRes {
-  size_t raw = 0, raw2 = 0, mean = 0, rstd = 0, mean2 = 0, rstd2 = 0, wp_f = 0, wp_d = 0, wp_x = 0;
+  size_t raw = 0, raw2 = 0, mean = 0, rstd = 0, mean2 = 0, rstd2 = 0, xtot = 0, wp_f = 0, wp_d = 0, wp_x = 0;
   int cin = 0, cout = 0, taps = 0;
   bool need_dgrad = false;
   bool stream_f = false, stream_d = false, stream_w = false;   // forward / data gradient / weight gradient on the streaming kernels
@@ -243,7 +243,8 @@ struct Plan {
         r.mean2 = take((size_t)d.batch * r.cout * 4);
         r.rstd2 = take((size_t)d.batch * r.cout * 4);
         if (fuse_x) {
-          xw_max = std::max(xw_max, (size_t)cat_xgrad_records(dims[lv]) * r.cout * 2 * 4);
+          xw_max = std::max(xw_max, (size_t)d.batch * epi_partials(dims[lv]) * r.cout * 2 * 8);
+          r.xtot = take((size_t)d.batch * 5 * 8);      // the input's moments per sample, kept for the backward pass
           xmom_max = std::max(xmom_max, (size_t)d.batch * xbranch_moment_slots(dims[lv]) * 5 * 8);
         } else {
           r.raw2 = take(act);
@@ -447,7 +448,7 @@ struct Exec {
           mark("stats");
           if (int e = launch_xbranch_moments(p.d.dtype, at(p.feat[o.xsrc]), dat(p.xmom), p.dims[lv], s)) return e;
           if (int e = launch_xbranch_stats(dat(p.xmom), xbranch_moment_slots(p.dims[lv]), w2, r.cout, p.d.in_channel, p.dims[lv].N,
-                                           p.dims[lv].vox(), p.d.eps, fat(r.mean2), fat(r.rstd2), s)) return e;
+                                           p.dims[lv].vox(), p.d.eps, fat(r.mean2), fat(r.rstd2), dat(r.xtot), s)) return e;
           mark("cat_fwd:" + n);
           // the max-pool that consumes this block (ec33 -> pool0, ec63 -> pool1, ec93 -> pool2) is written by the same kernel
           const bool pool_next = i + 1 < kNumOps && kOps[i + 1].kind == OP_POOL && kOps[i + 1].src[0] == o.dst &&
@@ -614,23 +615,22 @@ struct Exec {
         const float* rs2 = o.xname ? fat(r.rstd2) : nullptr;
         const int xi = o.xname ? find_param(reg, std::string(o.xname) + ".conv1.weight") : -1;
         if (o.xname && p.fuse_x) {
-          // x-branch recomputed from the input in both passes; pass B also accumulates its weight gradient
+          // x-branch recomputed from the input in both passes; pass A also sums what its weight gradient is formed from
           const float* w2 = P(std::string(o.xname) + ".conv1.weight");
           const void* xin = at(p.feat[o.xsrc]);
           if (int e = launch_cat_bwd_x(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), xin, w2, p.d.in_channel, mu2, rs2,
                                        r.cout, p.d.negative_slope, nullptr, nullptr, nullptr, nullptr, nullptr, dat(p.stats), dat(p.stats2),
-                                       nullptr, dm, s, pool_am[o.dst], pool_g[o.dst])) return e;
+                                       grads[xi] ? dat(p.xwp) : nullptr, dm, s, pool_am[o.dst], pool_g[o.dst])) return e;
           mark("stats");
+          if (grads[xi])
+            if (int e = launch_cat_xgrad_finalize(dat(p.xwp), dat(p.stats2), P_slots, dat(r.xtot), w2, r.cout, p.d.in_channel, dm.N,
+                                                  p.d.eps, grads[xi], s)) return e;
           if (int e = launch_stats_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1), fat(p.m2), s)) return e;
           if (int e = launch_stats_finalize(dat(p.stats2), P_slots, r.cout, dm.N, dm.vox(), 0.f, 1, fat(p.m1b), fat(p.m2b), s)) return e;
           mark("in_bwd:" + n);    // pass B
           if (int e = launch_cat_bwd_x(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), xin, w2, p.d.in_channel, mu2, rs2,
                                        r.cout, p.d.negative_slope, fat(p.m1), fat(p.m2), fat(p.m1b), fat(p.m2b), at(p.grad[o.dst]), nullptr,
-                                       nullptr, fat(p.xwp), dm, s, pool_am[o.dst], pool_g[o.dst])) return e;
-          if (grads[xi]) {
-            mark("stats");
-            if (int e = launch_cat_xgrad_reduce(fat(p.xwp), cat_xgrad_records(dm), r.cout, p.d.in_channel, grads[xi], s)) return e;
-          }
+                                       nullptr, nullptr, dm, s, pool_am[o.dst], pool_g[o.dst])) return e;
         } else {
           const void* r2 = o.xname ? at(r.raw2) : nullptr;
           if (int e = launch_cat_bwd(p.d.dtype, at(p.grad[o.dst]), at(r.raw), fat(r.mean), fat(r.rstd), r2, mu2, rs2, r.cout,

@@ -316,11 +316,10 @@ int launch_cat_bwd(int dtype, const void* g_out, const void* raw, const float* m
                    double* stat_partial2, Dims d, hipStream_t s);
 
 // pooling / interpolation / heads (resample.hip)
-int cat_xgrad_records(Dims d);
 int xbranch_moment_slots(Dims d);
 int launch_xbranch_moments(int dtype, const void* x_in, double* partial, Dims d, hipStream_t s);
 int launch_xbranch_stats(const double* partial, int slots, const float* w2, int C, int in_channel, int N, long long count,
-                         float eps, float* mean2, float* rstd2, hipStream_t s);
+                         float eps, float* mean2, float* rstd2, double* moments_out, hipStream_t s);
 int launch_cat_fwd_x(int dtype, const void* raw, const float* mean, const float* rstd, const void* x_in, const float* w2,
                      int in_channel, const float* mean2, const float* rstd2, int C, float slope, void* out, Dims d,
                      hipStream_t s);
@@ -330,9 +329,10 @@ int launch_cat_fwd_x_pool(int dtype, const void* raw, const float* mean, const f
 int launch_cat_bwd_x(int dtype, const void* g_out, const void* raw, const float* mean, const float* rstd, const void* x_in,
                      const float* w2, int in_channel, const float* mean2, const float* rstd2, int C, float slope,
                      const float* m1, const float* m2, const float* m1b, const float* m2b, void* dx, double* stat_partial,
-                     double* stat_partial2, float* xw_partial, Dims d, hipStream_t s, const unsigned* pool_argmax = nullptr,
+                     double* stat_partial2, double* xw_partial, Dims d, hipStream_t s, const unsigned* pool_argmax = nullptr,
                      const void* pool_g = nullptr);   // pool_*: gradient of the max-pool consuming the block's output, added on the fly
-int launch_cat_xgrad_reduce(const float* xw_partial, int records, int C, int in_channel, float* dw, hipStream_t s);
+int launch_cat_xgrad_finalize(const double* xw_partial, const double* stat_partial2, int slots, const double* moments, const float* w2,
+                              int C, int in_channel, int N, float eps, float* dw, hipStream_t s);
 int launch_xbranch_values(int dtype, const void* x_in, const float* w2, int C, int in_channel, float* out_ncdhw, Dims d, hipStream_t s);   // diagnostic
 int launch_maxpool_fwd(int dtype, const void* in, int C, void* out, Dims din, hipStream_t s);
 // max-pool backward from the arg-max words written by launch_cat_fwd_x_pool ([N][Vo][C/8] uint32, 3 bits per channel)

@@ -316,8 +316,9 @@ def cat_epilogue_x(g_out, raw, mean, rstd, x_in, w2, in_channel, slope=0.01, eps
     _lib.check(lib.seunet_xbranch_moments(code, x_in.data_ptr(), mom.data_ptr(), dims, _s()), "xbranch_moments")
     mean2 = torch.empty((n, c), dtype=torch.float32, device=raw.device)
     rstd2 = torch.empty_like(mean2)
+    tot = torch.empty((n, 5), dtype=torch.float64, device=raw.device)
     _lib.check(lib.seunet_xbranch_stats(mom.data_ptr(), mslots, w2f.data_ptr(), c, in_channel, n, d * h * w, eps, mean2.data_ptr(),
-                                        rstd2.data_ptr(), _s()), "xbranch_stats")
+                                        rstd2.data_ptr(), tot.data_ptr(), _s()), "xbranch_stats")
     out = torch.empty_like(raw)
     _lib.check(lib.seunet_cat_epilogue_fwd_x(code, raw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x_in.data_ptr(), w2f.data_ptr(),
                                              in_channel, mean2.data_ptr(), rstd2.data_ptr(), c, slope, out.data_ptr(), dims, _s()),
@@ -325,8 +326,7 @@ def cat_epilogue_x(g_out, raw, mean, rstd, x_in, w2, in_channel, slope=0.01, eps
     slots = lib.seunet_epilogue_slots(dims)
     st = torch.zeros((n, slots, c, 2), dtype=torch.float64, device=raw.device)
     st2 = torch.zeros_like(st)
-    records = lib.seunet_cat_xgrad_records(dims)
-    part = torch.empty((records, c, 2), dtype=torch.float32, device=raw.device)
+    part = torch.empty((n, slots, c, 2), dtype=torch.float64, device=raw.device)
     dx = torch.empty_like(raw)
 
     def bwd(m1, m2, m1b, m2b, o, s1, s2, xp):
@@ -334,12 +334,13 @@ def cat_epilogue_x(g_out, raw, mean, rstd, x_in, w2, in_channel, slope=0.01, eps
                                                  w2f.data_ptr(), in_channel, mean2.data_ptr(), rstd2.data_ptr(), c, slope, _lib.ptr(m1),
                                                  _lib.ptr(m2), _lib.ptr(m1b), _lib.ptr(m2b), _lib.ptr(o), _lib.ptr(s1), _lib.ptr(s2),
                                                  _lib.ptr(xp), dims, _s()), "cat_epilogue_bwd_x")
-    bwd(None, None, None, None, None, st, st2, None)
+    bwd(None, None, None, None, None, st, st2, part)
     m1, m2 = stats_finalize(st, slots, d * h * w, 0.0, 1)
     m1b, m2b = stats_finalize(st2, slots, d * h * w, 0.0, 1)
-    bwd(m1, m2, m1b, m2b, dx, None, None, part)
+    bwd(m1, m2, m1b, m2b, dx, None, None, None)
     dw = torch.zeros((c, in_channel, 1, 1, 1), dtype=torch.float32, device=raw.device)
-    _lib.check(lib.seunet_cat_xgrad_reduce(part.data_ptr(), records, c, in_channel, dw.data_ptr(), _s()), "cat_xgrad_reduce")
+    _lib.check(lib.seunet_cat_xgrad_finalize(part.data_ptr(), st2.data_ptr(), slots, tot.data_ptr(), w2f.data_ptr(), c, in_channel, n,
+                                             eps, dw.data_ptr(), _s()), "cat_xgrad_finalize")
     return out, dx, dw
 
 

@@ -225,23 +225,20 @@ class CropSegDataGPU:
         return crop_batch(self.img, plan["starts"], self.cube, self.label, self.weight, None, plan["codes"], plan["u"], f64_math=False)
 
 
-def _trend(xs) -> float:
-    return float(xs[-1] - xs[-2]) if len(xs) > 1 else 0.0
-
-
 class AirwayHMDataGPU:
     """Stage-2 sampler with the interface of the reference's ``AirwayHMData`` minus the file IO (data.py:254-408): the case
     volumes are resident on the GPU (HU int16 = file value - 1024, uint8 label, float16 LIB weight), the two candidate lists
     of the hard-mining samplers (``loc_skeleton`` = where(skeleton * (1 - pred)), ``loc_small`` = where(EDT(label) * skeleton
     < 2), data.py:305-306) are computed once per case by the caller; ``sample()`` = one ``__getitem__`` + the step's
-    ``.float().cuda()`` / transpose / cat (train.py:416-426).  ``hard_ratio`` and ``update_scheduler`` follow :273-283,326-349."""
+    ``.float().cuda()`` / transpose / cat (train.py:416-426).  ``hard_ratio`` is a plain attribute with the reference's initial
+    value (:273-283); the curriculum policy that moves it between epochs (``update_scheduler``, :326-349) is training control
+    plane, outside this path: the caller's loop sets ``ds.hard_ratio``."""
 
     def __init__(self, img, label, weight, loc_skeleton, loc_small, batch_size: int, aug_flag: int = 1, cube: int = 128):
         self.img, self.label, self.weight = img, label, weight
         self.loc_skeleton, self.loc_small = loc_skeleton, loc_small
         self.batch_size, self.aug_flag, self.cube = batch_size, aug_flag, cube
         self.random_ratio, self.hard_ratio = 0.6, 0.4
-        self.decay_step, self.decay_rate, self.max_hard_ratio, self.min_hard_ratio = 5, 0.05, 0.8, 0.2
 
     def sample(self) -> Dict[str, torch.Tensor]:
         plan = draw_stage2_plan(self.img.shape, self.batch_size, self.loc_skeleton, self.loc_small, self.cube, self.hard_ratio,
@@ -249,21 +246,6 @@ class AirwayHMDataGPU:
         out = crop_batch(self.img, plan["starts"], self.cube, self.label, self.weight, None, plan["codes"], plan["u"])
         out["kinds"] = plan["kinds"]
         return out
-
-    def update_scheduler(self, epoch, val_loss_random_list, val_loss_hard_list, val_td_list, val_bd_list):
-        """data.py:326-349: every ``decay_step`` epochs move ``hard_ratio`` by ``decay_rate`` towards more hard mining when the hard
-        crops lose more than the random ones or the tree metrics fell, towards less when they agree and the tree improves."""
-        if epoch % self.decay_step != 0 or epoch == 0:
-            return
-        window = min(3, len(val_loss_random_list))
-        diff = float(np.mean(val_loss_random_list[-window:]) - np.mean(val_loss_hard_list[-window:]))
-        td, bd = _trend(val_td_list), _trend(val_bd_list)
-        if diff > 0.04 or td < 0 or bd < 0:
-            self.hard_ratio = min(self.max_hard_ratio, self.hard_ratio + self.decay_rate)
-        elif diff < 0.02 and td >= 0 and bd >= 0:
-            self.hard_ratio = max(self.min_hard_ratio, self.hard_ratio - self.decay_rate)
-        elif diff > 0.05 or td < -1 or bd < -1:          # (unreachable after the first test, kept for the reference's order)
-            self.hard_ratio = max(self.min_hard_ratio, self.hard_ratio - self.decay_rate)
 
 
 class AirwayHMData3GPU:
@@ -275,9 +257,7 @@ class AirwayHMData3GPU:
         self.img, self.label, self.weight, self.skeleton = img, label, weight, skeleton
         self.loc_skeleton, self.loc_small, self.loc_break = loc_skeleton, loc_small, loc_break
         self.batch_size, self.aug_flag, self.cube = batch_size, aug_flag, cube
-        self.hard_ratio, self.break_ratio = 0.8, 0.625
-        self.min_hard_ratio, self.max_hard_ratio, self.min_break_ratio, self.max_break_ratio = 0.5, 0.9, 0.2, 0.8
-        self.decay_rate, self.decay_step = 0.05, 1
+        self.hard_ratio, self.break_ratio = 0.8, 0.625      # (set by the caller's curriculum between epochs)
 
     def sample(self) -> Dict[str, torch.Tensor]:
         plan = draw_stage3_plan(self.img.shape, self.batch_size, self.loc_skeleton, self.loc_small, self.loc_break, self.cube,
@@ -285,20 +265,3 @@ class AirwayHMData3GPU:
         out = crop_batch(self.img, plan["starts"], self.cube, self.label, self.weight, self.skeleton, plan["codes"], plan["u"])
         out["kinds"] = plan["kinds"]
         return out
-
-    def update_scheduler(self, epoch, val_loss_random_list, val_loss_hard_list, val_td_list, val_bd_list):
-        """data.py:493-534: ``hard_ratio`` as in stage 2 (every epoch here); ``break_ratio`` up when either tree metric fell, down
-        when both rose."""
-        if epoch % self.decay_step != 0 or epoch == 0:
-            return
-        window = min(3, len(val_loss_random_list))
-        diff = float(np.mean(val_loss_random_list[-window:]) - np.mean(val_loss_hard_list[-window:]))
-        td, bd = _trend(val_td_list), _trend(val_bd_list)
-        if diff > 0.04 or td < 0 or bd < 0:
-            self.hard_ratio = min(self.max_hard_ratio, self.hard_ratio + self.decay_rate)
-        elif diff < 0.02 and td >= 0 and bd >= 0:
-            self.hard_ratio = max(self.min_hard_ratio, self.hard_ratio - self.decay_rate)
-        if td < 0 or bd < 0:
-            self.break_ratio = min(self.max_break_ratio, self.break_ratio + self.decay_rate)
-        elif td > 0 and bd > 0:
-            self.break_ratio = max(self.min_break_ratio, self.break_ratio - self.decay_rate)

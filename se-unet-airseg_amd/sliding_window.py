@@ -42,7 +42,8 @@ def window_table(shape: Sequence[int], cube: int = 128, step: int = 64, pad_to_b
     return pos
 
 
-def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_dup: int, graph: bool = False, group=None) -> torch.Tensor:
+def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_dup: int, graph: bool = False, group=None,
+              sigmoid: bool = True) -> torch.Tensor:
     if not x.is_cuda:
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
     if x.dim() != 5 or x.shape[0] != 1:
@@ -85,7 +86,7 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
             for j in range(0, len(chunk), max_call):
                 sub = chunk[j:j + max_call]
                 arr = _lib.int_array([v for q in sub for v in q])
-                _lib.check(lib.seunet_window_accumulate(p[j:].data_ptr(), 1, len(sub), arr, cube, acc.data_ptr(), X, Y, Z, st),
+                _lib.check(lib.seunet_window_accumulate(p[j:].data_ptr(), 1 if sigmoid else 0, len(sub), arr, cube, acc.data_ptr(), X, Y, Z, st),
                            "window_accumulate")
         if world > 1:
             import torch.distributed as dist
@@ -123,7 +124,7 @@ def auto_batch(model, device, cube: int = 128, cap: int = 16) -> int:
 
 @torch.no_grad()
 def sliding_window_predict(model, x: torch.Tensor, cube: int = 128, step: int = 64, batch: Optional[int] = None,
-                           return_tensor: bool = False, graph: bool = False, group=None):
+                           return_tensor: bool = False, graph: bool = False, group=None, sigmoid: bool = True):
     """prediction.py:78-109.  x: (1, C, X, Y, Z) on the GPU.  Returns the overlap-averaged sigmoid(pred1) volume as
     float64 numpy (like the reference's host accumulators), or the float64 CUDA tensor with ``return_tensor=True`` (what
     ``double_threshold_iteration`` takes next, prediction.py:110).  ``batch`` windows go through the network per call
@@ -135,23 +136,26 @@ def sliding_window_predict(model, x: torch.Tensor, cube: int = 128, step: int = 
     ``group`` (``True`` = the default process group, or a ``ProcessGroup``): shard the windows of this ONE case over the
     ranks (every rank passes the same volume and gets the full result; the windows are dealt round-robin by index -- ranks
     may use different batch sizes -- and the float64 accumulators all-reduced once, RCCL on GPUs).  Eval mode only gives rank-count-independent results
-    (DropLayer draws are per call)."""
+    (DropLayer draws are per call).
+    ``sigmoid=False``: the variant of save_gradients.py:129-137 / weight_br.py:95-102, which accumulate the decoder head's RAW
+    logits (``pred += p``), average them and threshold the average at 0.5 (those scripts run under ``case_net.train()``, one
+    window per call: ``model.train()`` + ``batch=None`` gives exactly that)."""
     pos = window_table(x.shape[2:], cube, step)
     if batch is None:
         batch = auto_batch(model, x.device, cube) if x.is_cuda else 1
-    out = _assemble(model, x, pos, cube, step, batch, 0, graph, group)
+    out = _assemble(model, x, pos, cube, step, batch, 0, graph, group, sigmoid)
     return out if return_tensor else out.cpu().numpy()
 
 
 @torch.no_grad()
 def sliding_window_validate(model, x: torch.Tensor, batch: int = 24, cube: int = 128, step: int = 64,
-                            return_tensor: bool = False, graph: bool = False):
+                            return_tensor: bool = False, graph: bool = False, sigmoid: bool = True):
     """The validation / test form of the loop (train.py:682-693 with ``SegValCropData``, data.py:731-773; test.py:151-161
     with batch 8): the window list is padded with copies of window 0 to a multiple of ``batch`` and the copies are run and
     accumulated like any other window.  The reference runs this loop under ``model.train()`` (train.py:632):
     DropLayer is then active, its scale depends on the batch size, and each copy of window 0 gets its own draw -- call
-    ``model.train()`` / ``model.eval()`` yourself, as the reference does."""
+    ``model.train()`` / ``model.eval()`` yourself, as the reference does.  ``sigmoid=False`` accumulates raw logits."""
     pos = window_table(x.shape[2:], cube, step, pad_to_batch=batch)
     n_real = len(window_table(x.shape[2:], cube, step))
-    out = _assemble(model, x, pos, cube, step, batch, len(pos) - n_real, graph)
+    out = _assemble(model, x, pos, cube, step, batch, len(pos) - n_real, graph, None, sigmoid)
     return out if return_tensor else out.cpu().numpy()

@@ -116,28 +116,36 @@ def _check_grad_noise(err, ref_noise):
         (stats, ref, sorted(err.items(), key=lambda kv: -kv[1])[:6])
 
 
-def _check_vs_same_choice_f64(orc, m, b, stage, width_mult=1, tol=3e-5, what="", xtol=1e-3):
+def _check_vs_same_choice_f64(orc, m, b, stage, width_mult=1, tol=3e-5, what="", xtol=None, max_flip_frac=2e-6):
     """The flip-free network-level gradient gate (tests/forced_oracle.py): the float64 oracle is run with the LeakyReLU signs and
     max-pool arg-maxes that THIS forward of the HIP path took (read back from its workspace; the raw-input branches x33 / x63 /
     x93, which leave no tensor when in_channel <= 2, are recomputed by the device function the aggregation epilogue uses), and
     every parameter gradient of the HIP path must agree with it to rounding.  Measured on MI355X
     (profiles/r03_flip_census_32.md): median 3.5e-6, every tensor <= 1e-5 -- the same as the fp32 reference against float64
-    with ITS choices imposed (3.0e-6 / 7e-6).  `tol` = 3x the worst measured tensor.  `xtol` is for the weights of the three
-    raw-input branches: their gradient is sum_v draw[v] * x[v] with sum_v draw[v] = 0 (InstanceNorm backward) and x in [0, 1] far
-    from zero mean, so fp32 cancellation leaves 1.2e-4 at 2 x 32^3 in EVERY fp32 path with its choices imposed, the fp32
-    reference included (x93.conv1.weight: torch 1.21e-4, HIP 1.19e-4, profiles/r03_flip_census_32.md)."""
+    with ITS choices imposed (3.0e-6 / 7e-6).  `tol` = 3x the worst measured tensor.  `xtol` (default: `tol`) is for the weights of
+    the three raw-input branches: their gradient sum_v draw[v] * x[v] is what is left of terms that cancel (sum_v draw[v] = 0 and
+    sum_v draw[v] * xhat[v] = 0 with xhat linear in x), which costs every plain fp32 evaluation 1e-4 at 2 x 32^3 and 4e-4 ... 1.6e-3
+    at 128^3 (the fp32 reference with its choices imposed, tests/golden/bwd128_stage1.npz); the HIP path forms it in f64 from sums
+    (xw_finalize_kernel) and needs no allowance.
+    `max_flip_frac` bounds how many choices the gate imposes (fp32 mode): the path's forward may differ from float64's in at most
+    that fraction of the LeakyReLU signs + arg-maxes (measured 3e-7 ... 7e-7 at 32^3 ... 128^3, the fp32 reference alike), so a
+    forward that takes many wrong branches on near-zero inputs is not forgiven by having them imposed on the oracle."""
     import forced_oracle as FO
     _, _, inter = m.forward_with_intermediates(b["image"].cuda(), FO.LRELU_ORDER)
     signs, pools = FO.path_choices(inter)
-    of, _, _, lf, nsf, npf = FO.forced_step(orc, b, stage, signs, pools, width_mult=width_mult)
+    of, fe, fd, lf, nsf, npf = FO.forced_step(orc, b, stage, signs, pools, width_mult=width_mult)
     err = _rel_errors(m, of)
     v = np.array(list(err.values()))
-    print(f"{what} gradient rel-L2 vs float64 with the same {nsf} sign / {npf} arg-max flips imposed: median {np.median(v):.2e} "
-          f"p90 {np.percentile(v, 90):.2e} max {v.max():.2e}")
+    choices = sum(int(t.numel()) for t in signs.values()) + sum(int(t.numel()) for t in pools.values())
+    print(f"{what} gradient rel-L2 vs float64 with the same {nsf} sign / {npf} arg-max flips (of {choices} choices) imposed: "
+          f"median {np.median(v):.2e} p90 {np.percentile(v, 90):.2e} max {v.max():.2e}")
     print("   raw-input branches:", {k: "%.2e" % e for k, e in err.items() if k.startswith("x")})
+    if max_flip_frac is not None:
+        assert nsf + npf <= max(4, max_flip_frac * choices), (nsf, npf, choices)
+    xtol = tol if xtol is None else xtol
     bad = {k: e for k, e in err.items() if e > (xtol if k.startswith("x") else tol)}
     assert not bad and float(np.median(v)) <= tol / 3, (bad, float(np.median(v)))
-    return lf
+    return {"loss": lf, "err": err, "pred0": fe, "pred1": fd}
 
 
 @pytest.mark.parametrize("stage", [1, 3])
@@ -176,43 +184,58 @@ def test_forward_backward_vs_oracle_fp32(A, orc, golden_dir, stage, impl):
     print(f"stage {stage} impl {impl}: HIP-vs-f64 max {worst:.2e} median {med:.2e}; fp32-reference-vs-f64 max {max(ref_noise.values()):.2e}")
     _check_grad_noise(err, ref_noise)
     # ... and flip-free: against float64 with this forward's own discrete choices every tensor agrees to rounding
-    _check_vs_same_choice_f64(orc, m, b, stage, what=f"stage {stage} impl {impl}:")
+    # (impl 1, the naive cross-check kernels, materialises the raw-input branches and sums their weight gradient from the f32 draw
+    # like any plain fp32 evaluation: 1.2e-4 on x93, the fp32 reference's own figure at this size)
+    _check_vs_same_choice_f64(orc, m, b, stage, what=f"stage {stage} impl {impl}:", xtol=1e-3 if impl else None)
 
 
-def test_forward_backward_128_vs_oracle_fp32(A, orc):
+def test_forward_backward_128_vs_oracle_fp32(A, orc, golden_dir):
     """The size north_star names: one 1 x 2 x 128^3 patch (reference step train.py:594-603: forward, sigmoid, Dice on both
-    heads, backward) in the fp32 parity mode against the FLOAT64 oracle: logits and sigmoid outputs to the 1e-3 bar, the loss
-    to 1e-5, every parameter gradient inside the noise band the fp32 reference itself has against float64 on the same case
-    (median, printed) and -- the gate -- to rounding against the float64 oracle run with the SAME LeakyReLU-sign / arg-max choices
-    (_check_vs_same_choice_f64).  The two float64 oracle steps take a couple of minutes of host time."""
+    heads, backward) in the fp32 parity mode
+      * against the fixture the imported reference wrote at this size (oracle/make_golden_128.py -> bwd128_stage1.npz: strided
+        logit samples, loss, per-parameter gradient norms, SE_UNet.py:181-238 + train.py:594-602): logits 2e-3, loss 1e-5, gradient
+        norms to the flip-noise band (2e-2: the fp32 reference's small raw-input-branch gradients are themselves 1.6e-3 from
+        float64 under its own choices, and a handful of differing choices moves them by several 1e-3);
+      * against the FLOAT64 oracle run with the SAME LeakyReLU-sign / arg-max choices (_check_vs_same_choice_f64; at most 2e-6 of the
+        choices may differ from float64's own): logits and sigmoid outputs to the 1e-3 bar, the loss to 1e-5, every parameter
+        gradient to rounding (3e-5; the three raw-input branch weights 1e-3);
+      * the raw-input branch weights additionally against the fp32 REFERENCE's own same-choice error recorded in the fixture
+        (x33 8e-4, x63 1.6e-3, x93 4e-4): the HIP path must not be worse than twice that.
+    The float64 oracle step takes about a minute of host time (the plain, choice-free float64 and fp32 oracle runs this test used
+    to repeat for a printed noise band live in the fixture now)."""
+    golden = np.load(os.path.join(golden_dir, "bwd128_stage1.npz"))
     b = orc.synthetic_batch(1, (128, 128, 128), 2, seed=21)
-    o64 = orc.build_oracle(2, 1, 1, seed=0).double()
-    pe, pd = o64(b["image"].double())
-    l64 = orc.stage_loss(1, pe, pd, b["label"].double())
-    l64.backward()
-    pe, pd, l64 = pe.detach(), pd.detach(), float(l64.detach())
-    o32 = orc.build_oracle(2, 1, 1, seed=0)
-    qe, qd = o32(b["image"])
-    orc.stage_loss(1, qe, qd, b["label"]).backward()
-    ref_noise = _rel_errors(o32, o64)
-    del qe, qd
     m = build(A, orc, 2, "fp32")
     ge, gd = m(b["image"].cuda())
-    for got, ref, key in ((ge, pe, "pred0"), (gd, pd, "pred1")):
-        err = float((got.detach().cpu().double() - ref).abs().max())
-        serr = float((torch.sigmoid(got.detach().cpu().double()) - torch.sigmoid(ref)).abs().max())
-        print(f"128^3 {key}: logits max|err| {err:.3e}  sigmoid {serr:.3e}")
-        assert err < 2e-3 and serr < FP32_ATOL, f"{key}: logits {err:.3e} sigmoid {serr:.3e}"
+    for got, key in ((ge, "pred0"), (gd, "pred1")):         # the reference's own numbers at this size
+        gs = got.detach().cpu()
+        err = float((gs[0, 0, ::8, ::8, ::8] - torch.from_numpy(golden[key + "_s"])).abs().max())
+        print(f"128^3 {key}: max|logit - fp32 reference| on the fixture's samples {err:.3e}")
+        assert err < 2e-3, key
+        assert abs(float(gs.double().abs().sum()) - float(golden[key + "_abs"])) < 1e-4 * float(golden[key + "_abs"]), key
     loss = A.fused_stage_loss(1, ge, gd, b["label"].cuda())
     loss.backward()
-    assert abs(float(loss.detach()) - l64) < 1e-5, (float(loss.detach()), l64)
-    err = _rel_errors(m, o64)
-    v, r = np.array(list(err.values())), np.array(list(ref_noise.values()))
-    print("128^3 gradient rel-L2 vs plain f64 (median, p90, max): HIP %.2e %.2e %.2e | fp32 reference %.2e %.2e %.2e (flip noise; "
-          "the gate is the same-choice comparison below)" % (np.median(v), np.percentile(v, 90), v.max(), np.median(r), np.percentile(r, 90), r.max()))
-    assert float(np.median(v)) <= max(9e-4, 2 * float(np.median(r)))      # (the distribution's centre; its tail is where the flips fell)
-    del o64, o32
-    _check_vs_same_choice_f64(orc, m, b, 1, what="128^3:", xtol=1e-1)
+    assert abs(float(loss.detach()) - float(golden["loss"])) < 1e-5
+    for name, p in m.named_parameters():
+        if p.grad is not None and not name.endswith("conv1.bias"):
+            gn = float(golden[name + "|norm"])
+            assert abs(float(p.grad.double().norm()) - gn) <= 2e-2 * gn, (name, float(p.grad.double().norm()), gn)
+    # The raw-input branch weights: their gradient is what is left of terms that cancel to ~1e-6 of their size at this extent (in
+    # float64 the direct sum is only good to 1e-10), so ANY systematic 1e-10-class deviation of the incoming f32 gradient shows up
+    # at 1e-4: north_star's 1e-3 is the absolute bar, and the relative one is the fp32 reference's own same-choice error below.
+    # Measured on MI355X: x33 6.1e-6, x63 1.1e-4, x93 3.2e-4 (reference: 8.0e-4, 1.6e-3, 4.5e-4; this path before the f64
+    # formulation of round 4: x93 4.6e-2).
+    f = _check_vs_same_choice_f64(orc, m, b, 1, what="128^3:", xtol=1e-3)
+    for got, ref, key in ((ge, f["pred0"], "pred0"), (gd, f["pred1"], "pred1")):
+        err = float((got.detach().cpu().double() - ref).abs().max())
+        serr = float((torch.sigmoid(got.detach().cpu().double()) - torch.sigmoid(ref)).abs().max())
+        print(f"128^3 {key} vs float64 (same choices): logits max|err| {err:.3e}  sigmoid {serr:.3e}")
+        assert err < 2e-3 and serr < FP32_ATOL, f"{key}: logits {err:.3e} sigmoid {serr:.3e}"
+    assert abs(float(loss.detach()) - f["loss"]) < 1e-5, (float(loss.detach()), f["loss"])
+    for k in ("x33.conv1.weight", "x63.conv1.weight", "x93.conv1.weight"):
+        ref_err = float(golden[k + "|ref32_same_choice_err"])
+        print(f"   {k}: HIP {f['err'][k]:.2e} vs the fp32 reference's own same-choice error {ref_err:.2e}")
+        assert f["err"][k] <= 2 * ref_err, (k, f["err"][k], ref_err)
 
 
 def test_block_backward_exact_on_real_tensors_fp32(A, orc):
@@ -409,6 +432,26 @@ def test_sliding_window_matches_oracle_assembly(A, orc):
     assert float(np.abs(got - ref).max()) < FP32_ATOL
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_sliding_window_raw_logit_variant_matches_oracle(A, orc, train):
+    """save_gradients.py:129-137 / weight_br.py:95-102: the same loop accumulating the decoder head's RAW logits (no sigmoid),
+    averaged and thresholded at 0.5, run under ``case_net.train()`` (DropLayer active, one window per call, one CPU-generator
+    draw per window in both implementations)."""
+    m = build(A, orc, 2, "fp32", train=train)
+    o = orc.build_oracle(2, 1, 1, seed=0, train=train)
+    x = orc.synthetic_batch(1, (40, 32, 48), 2, seed=11)["image"]
+    torch.manual_seed(91)
+    got = A.sliding_window_predict(m, x.cuda(), cube=32, step=16, batch=None if train else 2, sigmoid=False)
+    torch.manual_seed(91)
+    ref = orc.sliding_window_predict(o, x, cube=32, step=16, sigmoid=False)
+    assert got.shape == ref.shape == (40, 32, 48)
+    assert float(np.abs(got - ref).max()) < 3e-3 and float(ref.min()) < 0.0               # (logits, not probabilities)
+    with_sig = A.sliding_window_predict(m.eval(), x.cuda(), cube=32, step=16, batch=2)
+    assert float(with_sig.min()) > 0.0 and float(got.min()) < 0.0
+    near = np.abs(ref - 0.5) < 1e-2                                                    # the scripts' threshold of the average
+    assert np.array_equal((got >= 0.5)[~near], (ref >= 0.5)[~near])
+
+
 def test_block_modules_standalone(A, orc):
     os.environ["SEUNET_DTYPE"] = "fp32"
     try:
@@ -500,7 +543,8 @@ def test_three_channel_input_takes_the_materialised_x_branch_fp32(A, orc):
         e = float((gp - gq).norm() / gq.norm())
         print(f"in_channel=3 {name}: rel-L2 vs fp32 oracle {e:.2e} (two fp32 paths: flip noise, informational)")
     # the gate: float64 with this forward's own choices imposed (here the x-branches are stored tensors)
-    _check_vs_same_choice_f64(orc, m, b, 1, what="in_channel=3:")
+    # (this path accumulates the x-branch weight gradient from the stored f32 draw like every plain fp32 evaluation: 1e-4-class)
+    _check_vs_same_choice_f64(orc, m, b, 1, what="in_channel=3:", xtol=1e-3)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
@@ -635,7 +679,7 @@ def test_bf16_mode_trains_like_fp32_mode(A, orc):
     assert np.abs(f - h).max() <= 5e-3
 
 
-def _dp_worker(rank, world, port, backend, q, overlap=False):
+def _dp_worker(rank, world, port, backend, q, overlap=False, dtype="fp32", poison=False):
     import os as _os
     import sys as _sys
     _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -654,12 +698,19 @@ def _dp_worker(rank, world, port, backend, q, overlap=False):
         dev = _t.device("cuda", rank if backend == "nccl" else 0)
         _t.cuda.set_device(dev)
         b = _orc.synthetic_batch(2, (32, 32, 32), 2, seed=3)
-        m = _A.SE_UNet(2, 1, act_dtype="fp32")
+        m = _A.SE_UNet(2, 1, act_dtype=dtype)
         m.load_state_dict(_orc.deterministic_state_dict(2, 1, 1, seed=0))
         m = m.to(dev).eval()
         x, lab = b["image"][rank:rank + 1].to(dev), b["label"][rank:rank + 1].to(dev)
         if overlap:      # the exchange runs inside backward(): decoder bucket on a side stream, the rest after the backward
-            m.grad_sync = _ddp.GradSync(timing=True)
+            sync_cls = _ddp.GradSync
+            if poison:   # ONE rank's buffer holds an inf before the exchange (a scaled fp16 gradient that left half precision's range)
+                class sync_cls(_ddp.GradSync):
+                    def exchange(self, flat, split, ev):
+                        if rank == 1:
+                            flat[:1].fill_(float("inf"))
+                        super().exchange(flat, split, ev)
+            m.grad_sync = sync_cls(timing=True)
             assert m.grad_sync.decoder_event().cuda_event != 0    # (a torch event has no handle before its first record)
         e, d = m(x)
         loss = _A.fused_stage_loss(1, e, d, lab, group=True)      # global-batch ratio: sums all-reduced first
@@ -674,32 +725,40 @@ def _dp_worker(rank, world, port, backend, q, overlap=False):
         if overlap:
             assert len(m.grad_sync.elapsed_ms()) == 1
         out = {k: p.grad.cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}   # by value (the worker exits)
-        q.put((rank, float(loss.detach()), bool(zero_copy), int(n), out if rank == 0 else None))
+        if poison:
+            out = {"overflow_steps": int(m.overflow_steps), "max_abs": max(float(np.abs(v).max()) for v in out.values())}
+        q.put((rank, float(loss.detach()), bool(zero_copy), int(n), out if (rank == 0 or poison) else None))
         _dist.barrier()
         _dist.destroy_process_group()
     except Exception as ex:     # report instead of hanging the parent
         q.put((rank, repr(ex), False, 0, None))
 
 
-def _run_dp_equivalence(A, orc, backend, overlap=False):
+def _spawn_dp(backend, overlap, dtype="fp32", poison=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000 + (7 if backend == "nccl" else 0) + (13 if overlap else 0)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, backend, q, overlap)) for r in range(2)]
+    port = 29500 + os.getpid() % 2000 + (7 if backend == "nccl" else 0) + (13 if overlap else 0) + {"fp32": 0, "bf16": 29, "fp16": 53}[dtype] \
+        + (101 if poison else 0)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, backend, q, overlap, dtype, poison)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(120)
     assert all(isinstance(r[1], float) for r in res), res
+    return res
+
+
+def _run_dp_equivalence(A, orc, backend, overlap=False, dtype="fp32", tol=1e-4, loss_tol=1e-6):
+    res = _spawn_dp(backend, overlap, dtype)
     # single process, batch 2
     b = orc.synthetic_batch(2, (32, 32, 32), 2, seed=3)
-    m = build(A, orc, 2, "fp32")
+    m = build(A, orc, 2, dtype)
     e, d = m(b["image"].cuda())
     loss = A.fused_stage_loss(1, e, d, b["label"].cuda())
     loss.backward()
-    assert abs(res[0][1] - float(loss.detach())) < 1e-6 and abs(res[1][1] - float(loss.detach())) < 1e-6
+    assert abs(res[0][1] - float(loss.detach())) < loss_tol and abs(res[1][1] - float(loss.detach())) < loss_tol
     assert res[0][2] and res[1][2], "gradients of a real backward are not one contiguous bucket"
     assert res[0][3] == 1_520_314 - 768
     worst = 0.0
@@ -711,8 +770,8 @@ def _run_dp_equivalence(A, orc, backend, overlap=False):
             assert float(got.abs().max()) <= 1e-6
             continue
         worst = max(worst, float((got - ref).norm() / max(float(ref.norm()), 1e-30)))
-    print(f"1 GPU x B=2 vs 2 ranks x B=1 ({backend}): worst gradient rel-L2 {worst:.2e}")
-    assert worst < 1e-4
+    print(f"1 GPU x B=2 vs 2 ranks x B=1 ({backend}, {dtype}, {'overlapped' if overlap else 'serial'}): worst gradient rel-L2 {worst:.2e}")
+    assert worst < tol
 
 
 def test_data_parallel_two_ranks_equal_one_rank_batch2_gloo_shared_gpu(A, orc):
@@ -729,12 +788,39 @@ def test_data_parallel_overlapped_exchange_equals_one_rank_batch2_gloo_shared_gp
     _run_dp_equivalence(A, orc, "gloo", overlap=True)
 
 
+# 16-bit storage modes (BASELINE configs[2] is bf16, configs[4] fp16).  The sample-wise kernels give the same bits for a sample
+# whatever the batch it sits in, except the InstanceNorm partial-sum order (a function of the batch size), so 1 x B=2 and 2 x B=1
+# differ by a rounding of the statistics that a 16-bit store then either keeps or amplifies to one unit in the last place:
+# the bound is the storage format's own step (measured on MI355X: see the printed value), far below the mode's distance from
+# float64 (bf16 5e-2, fp16 6e-3) and three orders above what a missing or doubled exchange would give (rel-L2 ~ 1).
+DP_16BIT = [("bf16", 2e-2), ("fp16", 3e-3)]
+
+
 @pytest.mark.parametrize("overlap", [False, True])
-def test_data_parallel_two_gpus_equal_one_gpu_batch2_rccl(A, orc, overlap):
+@pytest.mark.parametrize("dtype,tol", DP_16BIT)
+def test_data_parallel_16bit_modes_equal_one_rank_batch2_gloo_shared_gpu(A, orc, dtype, tol, overlap):
+    """train.py:577's DataParallel reduce in the benchmark dtypes: serial (``allreduce_gradients``) and overlapped
+    (``GradSync``, which with fp16's loss scale reduces the SCALED buffer and tests finiteness on the global sum)."""
+    _run_dp_equivalence(A, orc, "gloo", overlap=overlap, dtype=dtype, tol=tol, loss_tol=2e-3)
+
+
+def test_data_parallel_fp16_overflow_on_one_rank_skips_the_step_on_all_ranks(A, orc):
+    """fp16 storage carries gradients times a static loss scale; a backward whose scaled gradients overflow is dropped.  Under data
+    parallelism the decision must be global or the ranks' weights diverge: the exchange sums the scaled buffers FIRST, so one
+    rank's inf is every rank's inf.  Rank 1 plants an inf in its buffer just before the exchange: both ranks must end with
+    all-zero gradients and overflow_steps == 1."""
+    res = _spawn_dp("gloo", True, "fp16", poison=True)
+    for r in res:
+        assert r[4] == {"overflow_steps": 1, "max_abs": 0.0}, res
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4)] + DP_16BIT)
+def test_data_parallel_two_gpus_equal_one_gpu_batch2_rccl(A, orc, overlap, dtype, tol):
     """The same equivalence over RCCL with one GPU per rank (skipped on a single-GPU box)."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
-    _run_dp_equivalence(A, orc, "nccl", overlap=overlap)
+    _run_dp_equivalence(A, orc, "nccl", overlap=overlap, dtype=dtype, tol=tol, loss_tol=1e-6 if dtype == "fp32" else 2e-3)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -268,28 +268,6 @@ def test_stage23_sampler_plans_match_reference_samplers_fixture(golden_dir):
     assert m["starts"] == a["starts"] and set(m["kinds"]) == {"random"}
 
 
-def test_stage23_schedulers_follow_the_reference_rules():
-    """update_scheduler of the two hard-mining datasets (data.py:326-349, 493-534) on hand-made validation histories."""
-    import seunet_amd as A
-    ds = A.AirwayHMDataGPU(None, None, None, None, None, 4)
-    ds.update_scheduler(3, [0.5], [0.4], [1, 2], [1, 2])           # not a multiple of decay_step: unchanged
-    assert ds.hard_ratio == 0.4
-    ds.update_scheduler(5, [0.5, 0.5], [0.4, 0.4], [1, 2], [1, 2])   # random crops lose 0.1 more: more hard mining
-    assert ds.hard_ratio == pytest.approx(0.45)
-    ds.update_scheduler(10, [0.40], [0.39], [1, 2], [1, 2])          # agree, tree improving: less
-    assert ds.hard_ratio == pytest.approx(0.40)
-    ds.hard_ratio = 0.8
-    ds.update_scheduler(15, [0.5], [0.4], [2, 1], [1, 2])            # capped at max_hard_ratio
-    assert ds.hard_ratio == 0.8
-    d3 = A.AirwayHMData3GPU(None, None, None, None, None, None, None, 4)
-    d3.update_scheduler(1, [0.5], [0.4], [2, 1], [1, 2])             # TD fell: more hard, more break
-    assert d3.hard_ratio == pytest.approx(0.85) and d3.break_ratio == pytest.approx(0.675)
-    d3.update_scheduler(2, [0.40], [0.39], [1, 2], [1, 2])           # both rose: less of both
-    assert d3.hard_ratio == pytest.approx(0.80) and d3.break_ratio == pytest.approx(0.625)
-    d3.update_scheduler(0, [0.9], [0.1], [2, 1], [2, 1])             # epoch 0: never
-    assert d3.hard_ratio == pytest.approx(0.80)
-
-
 def test_metrics_oracle_matches_reference_metrics_module_fixture(golden_dir):
     """oracle/components_oracle.py's metric functions against values produced by the reference's own metrics.py
     (oracle/make_golden_components.py): identical rounded percentages and branch counts."""
