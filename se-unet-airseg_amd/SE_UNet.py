@@ -38,6 +38,19 @@ from . import _lib
 
 config = {}   # reference SE_UNet.py:7
 
+# Test hook: byte value every freshly allocated workspace / output / gradient buffer is filled with before the library is called
+# (None = leave torch.empty's contents).  The library must never read a byte it has not written in the same pass: a run over
+# 0xFF-filled buffers (NaN patterns in every storage type) has to give the bits of a run over zero-filled ones
+# (tests/test_net_gpu.py::test_results_do_not_depend_on_the_prior_contents_of_the_workspace).
+_DEBUG_FILL: Optional[int] = None
+
+
+def _fresh(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if _DEBUG_FILL is not None:
+        t.view(torch.uint8).fill_(_DEBUG_FILL)
+    return t
+
 
 def _default_dtype() -> str:
     return os.environ.get("SEUNET_DTYPE", "bf16")
@@ -150,7 +163,7 @@ def alloc_flat_grads(params, dead, device, names=None):
     if names is not None:
         idx = [i for i in idx if not _is_decoder(names[i])] + [i for i in idx if _is_decoder(names[i])]
     sizes = {i: (0 if dead[i] else params[i].numel()) for i in idx}
-    flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=device)
+    flat = _fresh(sum(sizes.values()), torch.float32, device)
     grads, off, split = [None] * len(params), 0, None
     for i in idx:
         if names is not None and split is None and _is_decoder(names[i]):
@@ -172,9 +185,9 @@ class _SEUNetFunction(torch.autograd.Function):
             ws_bytes = lib.seunet_net_workspace_bytes(C.byref(desc))
             if ws_bytes == 0:
                 raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-            pred0 = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
-            pred1 = torch.empty_like(pred0)
+            ws = _fresh(ws_bytes, torch.uint8, x.device)
+            pred0 = _fresh((b, 1, d, h, w), torch.float32, x.device)
+            pred1 = _fresh((b, 1, d, h, w), torch.float32, x.device)
             plist = [p.detach().contiguous() for p in params]
             for p in plist:
                 if p.device != x.device:

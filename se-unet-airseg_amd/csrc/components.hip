@@ -112,7 +112,7 @@ cc_count_kernel(const int* __restrict__ L, long long n, unsigned int* __restrict
   const long long i = blockIdx.x * 256ll + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int r = i < n ? L[i] : -1;
-  const int prev = __shfl_up(r, 1, 64);
+  const int prev = dpp_settle(__shfl_up(r, 1, 64));
   const bool lead = r >= 0 && (lane == 0 || prev != r);
   const u64 leaders = __ballot(lead), fg = __ballot(r >= 0);
   if (!lead) return;
@@ -134,7 +134,7 @@ cc_select_kernel(const int* __restrict__ L, const unsigned int* __restrict__ cnt
   // wave maximum first: one atomic per wave
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    const u64 o = __shfl_xor(key, off, 64);
+    const u64 o = shfl_xor_settled(key, off);
     key = o > key ? o : key;
   }
   if ((threadIdx.x & 63) == 0 && key) atomicMax(pass == 0 ? &sel->best : &sel->second, key);
@@ -261,11 +261,11 @@ metric_sums_kernel(const unsigned char* __restrict__ pred, const unsigned char* 
   for (int q = 0; q < 5; ++q) {
     u64 v = s[q];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = 32; off >= 1; off >>= 1) v += shfl_xor_settled(v, off);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sums[q], v);
   }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+  for (int off = 32; off >= 1; off >>= 1) { const int o = shfl_xor_settled(mx, off); mx = o > mx ? o : mx; }
   if ((threadIdx.x & 63) == 0 && mx) atomicMax(max_id, mx);
 }
 

@@ -81,17 +81,17 @@ template <> struct Frag<float> { static constexpr int KC = 8, KSTEPS = 4; };
 template <int CTRL> __device__ __forceinline__ float xlane_dpp(float v) { return dpp_fetch<CTRL>(v); }
 template <int CTRL> __device__ __forceinline__ double xlane_dpp(double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  const unsigned lo = (unsigned)dpp_fetch_bits<CTRL>((int)(unsigned)u);
+  const unsigned hi = (unsigned)dpp_fetch_bits<CTRL>((int)(unsigned)(u >> 32));
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ float xlane_swz16(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+  return dpp_settle(__builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)));
 }
 __device__ __forceinline__ double xlane_swz16(double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, 0x401F);
-  const unsigned hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), 0x401F);
+  const unsigned lo = (unsigned)dpp_settle(__builtin_amdgcn_ds_swizzle((int)(unsigned)u, 0x401F));
+  const unsigned hi = (unsigned)dpp_settle(__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), 0x401F));
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
@@ -374,7 +374,8 @@ conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) cntf += vok[ms] ? 1.f : 0.f;
     cntf += dpp_fetch<0xB1>(cntf); cntf += dpp_fetch<0x4E>(cntf); cntf += dpp_fetch<0x141>(cntf); cntf += dpp_fetch<0x140>(cntf);
-    cntf += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, cntf), 0x401F));   // xor 16
+    cntf = dpp_settle(cntf);      // (see seunet_common.h: nothing may narrow EXEC right behind a DPP fetch)
+    cntf += dpp_settle(__builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, cntf), 0x401F)));   // xor 16
     const int j = col, rj = j & 15;
     // partial-sum type: f32 for bf16 activations (the stored tensor keeps 8 bits of mantissa anyway); f64 in the f32
     // parity mode, whose gradients are ill-conditioned enough to see an f32 reduction tree
@@ -386,7 +387,7 @@ conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // the shift: this channel's value at the half-wave's first lane, y-row 0 (any value of the channel will do)
-        v0[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane & 32) * 4, __builtin_bit_cast(int, acc[0][ns][r])));
+        v0[r] = dpp_settle(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane & 32) * 4, __builtin_bit_cast(int, acc[0][ns][r]))));
         R p1 = 0, p2 = 0;
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -427,7 +428,7 @@ conv_igemm_kernel(ConvKArgs a) {
       float sh = v0[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) sh = (rj == r) ? v0[r] : sh;
-      const R mine = val[0];
+      const R mine = dpp_settle(val[0]);
       const R s_of_q = xlane_swz16(mine);   // lane j ^ 16: the sum that belongs to this lane's sum of squares
       const double d0 = (double)sh, dc = (double)cntf;
       const double tot = j < 16 ? (double)mine + dc * d0

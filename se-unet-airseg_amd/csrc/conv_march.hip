@@ -473,7 +473,7 @@ conv_march_kernel(MarchArgs a) {
       for (int e = 0; e < 4; ++e) {
         double t1 = stot[e * 256], t2 = stot[(4 + e) * 256];
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
+        for (int off = 1; off < 16; off <<= 1) { t1 += shfl_xor_settled(t1, off); t2 += shfl_xor_settled(t2, off); }
         if (n16 == 0) {
           red[(wave * 16 + 4 * g + e) * 2] = t1;
           red[(wave * 16 + 4 * g + e) * 2 + 1] = t2;

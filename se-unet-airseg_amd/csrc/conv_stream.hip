@@ -378,7 +378,7 @@ conv_stream_kernel(StreamArgs a) {
       double t2 = (double)s2[FWD ? e : 0];
       constexpr int GROUP = COUTP == 32 ? 32 : 16;
 #pragma unroll
-      for (int off = 1; off < GROUP; off <<= 1) { t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
+      for (int off = 1; off < GROUP; off <<= 1) { t1 += shfl_xor_settled(t1, off); t2 += shfl_xor_settled(t2, off); }
       if (fn == 0) {
         const int c = chan(e);
         red[(wave * COUTP + c) * 2] = t1;

@@ -25,6 +25,14 @@ template <typename T> __device__ __forceinline__ float round_to(float v) {
   else return unpack_lo<T>(pack2<T>(v, 0.f));
 }
 
+// The spatial gates' sigmoid.  f32 storage (the 1e-3 parity mode): expf and an IEEE division.  16-bit storage: one v_exp_f32 and
+// one v_rcp_f32 (1 ulp each) instead of ~25 instructions of range reduction and division fix-up -- the gate multiplies values that
+// keep 8 / 11 mantissa bits; forward and both backward passes use the same function, so a gate is the same number everywhere.
+template <typename T> __device__ __forceinline__ float gate_sigmoid(float z) {
+  if constexpr (sizeof(T) == 4) return 1.f / (1.f + expf(-z));
+  else return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z));
+}
+
 static constexpr int EPI_THREADS = 256;
 
 int epi_partials(Dims d) {
@@ -95,8 +103,8 @@ __device__ __forceinline__ void stats_finalize_body(int idx, const double* __res
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    s1 += __shfl_xor(s1, off, 64);
-    s2 += __shfl_xor(s2, off, 64);
+    s1 += shfl_xor_settled(s1, off);
+    s2 += shfl_xor_settled(s2, off);
   }
   __shared__ double w1[4], w2[4];
   if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = s1; w2[threadIdx.x >> 6] = s2; }
@@ -168,7 +176,7 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       a[j] = xh > 0.f ? xh : xh * slope;
       d1 += wse[j] * a[j];
     }
-    const float g1 = 1.f / (1.f + expf(-group_sum<LPV>(d1)));
+    const float g1 = gate_sigmoid<T>(group_sum<LPV>(d1));
     float d2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -176,7 +184,7 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       d2 += wse2[j] * e[j];
     }
     if (G2) {
-      const float g2 = 1.f / (1.f + expf(-group_sum<LPV>(d2)));
+      const float g2 = gate_sigmoid<T>(group_sum<LPV>(d2));
 #pragma unroll
       for (int j = 0; j < 8; ++j) e[j] *= g2;
     }
@@ -206,7 +214,13 @@ sse_fwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
 //                           enough) + the gate / side / head parameter gradients
 //   APPLY = true  (pass B): draw = rstd * (dxhat - m1 - xhat * m2), rounded once, stored over g_e
 // ----------------------------------------------------------------------------------
-template <typename T, int LPV, bool G2, bool APPLY>
+// LEVEL: the side gradient arrives as ONE value per voxel, the gradient g of the head's level map (training: always), so
+//   d side_k = hw_k * g with hw_k = head weight x DropLayer scale of the sample.  Everything that is linear in it is then taken out
+//   of the voxel loop: de += g * (w20 hw0 + w21 hw1) with the bracket formed once per thread, and the gradients of the side conv,
+//   its bias and the head weights all follow from G[c] = sum_v g e[c] and sum_v g at the end of the block (d w2k[c] = hw_k G[c],
+//   d b2k = hw_k sum g, d head_k = drop_k (sum_c w2k[c] G[c] + b2k sum g)) -- no per-voxel side values, no second accumulator set.
+//   Pass A of the one-gate C = 32 block: 266 -> ~200 instructions per voxel group, under its HBM time.
+template <typename T, int LPV, bool G2, bool APPLY, bool LEVEL>
 __global__ void __launch_bounds__(EPI_THREADS, (APPLY || G2) ? 1 : 3)
 sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
                const float* __restrict__ rstd, int C, SseParams p, SseBwdIn g, SseHead head,
@@ -252,6 +266,9 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
     am2[j] = APPLY ? m2p[n * C + c0 + j] : 0.f;
   }
   float adb0 = 0.f, adb1 = 0.f, adh0 = 0.f, adh1 = 0.f;
+  float wc[8], sgl = 0.f;      // LEVEL: w20 hw0 + w21 hw1; sum of g (aw20 doubles as G)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wc[j] = w20[j] * hw0 + w21[j] * hw1;
 
   // software pipeline: the loads of voxel v + stride are issued before voxel v is computed
   const long long stride = (long long)P * VPB;
@@ -282,38 +299,48 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
       a[j] = xh[j] > 0.f ? xh[j] : xh[j] * slope;
       d1 += wse[j] * a[j];
     }
-    const float g1 = 1.f / (1.f + expf(-group_sum<LPV>(d1)));
+    const float g1 = gate_sigmoid<T>(group_sum<LPV>(d1));
     float d2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { b[j] = a[j] * g1; d2 += wse2[j] * b[j]; }
     float g2 = 1.f;
-    if (G2) g2 = 1.f / (1.f + expf(-group_sum<LPV>(d2)));
+    if (G2) g2 = gate_sigmoid<T>(group_sum<LPV>(d2));
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = G2 ? b[j] * g2 : b[j];
 
     // gradient arriving through the 2-channel side output
-    float ds0 = 0.f, ds1 = 0.f;
-    if (g.g_level) {
-      ds0 = hw0 * gl;
-      ds1 = hw1 * gl;
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s0 += w20[j] * e[j]; s1 += w21[j] * e[j]; }
-      s0 = group_sum<LPV>(s0) + b20;
-      s1 = group_sum<LPV>(s1) + b21;
-      if (!APPLY && cg == 0) { adh0 += gl * dr0 * s0; adh1 += gl * dr1 * s1; }
-    } else if (g.g_side) {
-      ds0 = gs0;
-      ds1 = gs1;
-    }
-    if (cg == 0) { adb0 += ds0; adb1 += ds1; }
     float t2 = 0.f;
+    if (LEVEL) {
+      if (!APPLY) sgl += gl;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      de[j] += w20[j] * ds0 + w21[j] * ds1;
-      aw20[j] += ds0 * e[j];
-      aw21[j] += ds1 * e[j];
-      t2 += de[j] * b[j];
+      for (int j = 0; j < 8; ++j) {
+        de[j] += gl * wc[j];
+        if (!APPLY) aw20[j] += gl * e[j];
+        t2 += de[j] * b[j];
+      }
+    } else {
+      float ds0 = 0.f, ds1 = 0.f;
+      if (g.g_level) {
+        ds0 = hw0 * gl;
+        ds1 = hw1 * gl;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0 += w20[j] * e[j]; s1 += w21[j] * e[j]; }
+        s0 = group_sum<LPV>(s0) + b20;
+        s1 = group_sum<LPV>(s1) + b21;
+        if (!APPLY && cg == 0) { adh0 += gl * dr0 * s0; adh1 += gl * dr1 * s1; }
+      } else if (g.g_side) {
+        ds0 = gs0;
+        ds1 = gs1;
+      }
+      if (cg == 0) { adb0 += ds0; adb1 += ds1; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        de[j] += w20[j] * ds0 + w21[j] * ds1;
+        aw20[j] += ds0 * e[j];
+        aw21[j] += ds1 * e[j];
+        t2 += de[j] * b[j];
+      }
     }
     if (G2) {  // e = b * g2, g2 = sigmoid(<w_se2, b>)
       const float q2 = group_sum<LPV>(t2) * g2 * (1.f - g2);
@@ -353,6 +380,21 @@ sse_bwd_kernel(const T* __restrict__ raw, const float* __restrict__ mean,
   }
 #undef SSE_BWD_FETCH
   if (APPLY) return;
+  if (LEVEL) {     // aw20 holds G[c] = sum_v g e[c]: the side / bias / head gradients of this thread's voxels follow from it
+    float h0 = cg == 0 ? b20 * sgl : 0.f, h1 = cg == 0 ? b21 * sgl : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float G = aw20[j];
+      h0 += w20[j] * G;
+      h1 += w21[j] * G;
+      aw20[j] = hw0 * G;
+      aw21[j] = hw1 * G;
+    }
+    adh0 = dr0 * h0;
+    adh1 = dr1 * h1;
+    adb0 = cg == 0 ? hw0 * sgl : 0.f;
+    adb1 = cg == 0 ? hw1 * sgl : 0.f;
+  }
   double sdx[8], sdxx[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -409,7 +451,7 @@ __device__ __forceinline__ void pgrad_reduce_body(int blk, const float* __restri
   double s = 0.0;
   for (int r = lane; r < records; r += 64) s += (double)pg[(long long)r * K + k];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int off = 32; off >= 1; off >>= 1) s += shfl_xor_settled(s, off);
   if (lane != 0) return;
   const float v = (float)s;
   if (k < C) { if (dw_se) dw_se[k] = v; }
@@ -455,7 +497,7 @@ input_moments_kernel(const T* __restrict__ xin, double* __restrict__ partial, lo
   for (int k = 0; k < 5; ++k) {
     double r = s[k];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+    for (int off = 32; off >= 1; off >>= 1) r += shfl_xor_settled(r, off);
     if (lane == 0) red[wave][k] = r;
   }
   __syncthreads();
@@ -481,7 +523,7 @@ xbranch_stats_kernel(const double* __restrict__ partial, int slots, const float*
   for (int k = 0; k < 5; ++k) {
     double r = s[k];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+    for (int off = 32; off >= 1; off >>= 1) r += shfl_xor_settled(r, off);
     if (lane == 0) red[wave][k] = r;
   }
   __syncthreads();
@@ -808,10 +850,13 @@ static int sse_bwd_t(const void* raw, const float* mean, const float* rstd, int 
                      float* pgrad_partial, Dims d, hipStream_t s) {
   dim3 grid(epi_partials(d) * (APPLY ? 4 : 1), d.N);
   const bool g2 = p.w_se2 != nullptr;
+  const bool level = g.g_level != nullptr;
+#define SEUNET_SSE_BWD(G2V, LV) sse_bwd_kernel<T, LPV, G2V, APPLY, LV><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, C, p, g, head, m1, m2, (T*)out, stat_partial, pgrad_partial, d.vox())
   SEUNET_LPV_SWITCH(C / 8, {
-    if (g2) sse_bwd_kernel<T, LPV, true, APPLY><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, C, p, g, head, m1, m2, (T*)out, stat_partial, pgrad_partial, d.vox());
-    else sse_bwd_kernel<T, LPV, false, APPLY><<<grid, EPI_THREADS, 0, s>>>((const T*)raw, mean, rstd, C, p, g, head, m1, m2, (T*)out, stat_partial, pgrad_partial, d.vox());
+    if (g2) { if (level) SEUNET_SSE_BWD(true, true); else SEUNET_SSE_BWD(true, false); }
+    else { if (level) SEUNET_SSE_BWD(false, true); else SEUNET_SSE_BWD(false, false); }
   });
+#undef SEUNET_SSE_BWD
   SEUNET_LAUNCH_CHECK();
   return 0;
 }
@@ -875,7 +920,7 @@ xw_finalize_kernel(const double* __restrict__ xw_partial, const double* __restri
     for (int k = 0; k < 3; ++k) {
       double r = s[k];
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+      for (int off = 32; off >= 1; off >>= 1) r += shfl_xor_settled(r, off);
       if (lane == 0) red[wave][k] = r;
     }
     __syncthreads();

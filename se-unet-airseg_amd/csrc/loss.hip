@@ -66,7 +66,7 @@ loss_sums_kernel(const float* __restrict__ pred, int apply_sigmoid, const float*
   for (int k = 0; k < SEUNET_LOSS_NSUMS; ++k) {
     float v = s[k];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = 32; off >= 1; off >>= 1) v += shfl_xor_settled(v, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
@@ -83,7 +83,7 @@ loss_sums_final_kernel(const float* __restrict__ partial, int blocks, double* __
   double s = 0.0;
   for (int b = lane; b < blocks; b += 64) s += (double)partial[b * SEUNET_LOSS_NSUMS + k];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int off = 32; off >= 1; off >>= 1) s += shfl_xor_settled(s, off);
   if (lane == 0) sums[k] = s;
 }
 

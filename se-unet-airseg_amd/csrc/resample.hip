@@ -1026,7 +1026,7 @@ head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, fl
   const bool fast = nent <= 128 && __all(ca <= HB_KA && cb <= HB_KB && fa + HB_KA <= RW && fb + HB_KB <= RW);   // (wave-uniform)
   int ka = 0, kb = 0;                                    // taps to walk: the wave's maxima, rounded up to 4
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { ca = max(ca, __shfl_xor(ca, off, 64)); cb = max(cb, __shfl_xor(cb, off, 64)); }
+  for (int off = 32; off >= 1; off >>= 1) { ca = max(ca, shfl_xor_settled(ca, off)); cb = max(cb, shfl_xor_settled(cb, off)); }
   ka = (ca + 3) & ~3; kb = (cb + 3) & ~3;
   const int la = e0 < ebase[2] ? 1 : (e0 < ebase[3] ? 2 : 3), lb = e1 < ebase[2] ? 1 : (e1 < ebase[3] ? 2 : 3);
   float* const outa = e0 < nent ? (la == 1 ? t1a : (la == 2 ? t1b : t1c)) : nullptr;
@@ -1087,7 +1087,7 @@ head_bwd_x_multi_kernel(const float* __restrict__ g, float* __restrict__ t1a, fl
   }
   if (bias_part != nullptr) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    for (int off = 32; off >= 1; off >>= 1) sum += shfl_xor_settled(sum, off);
     __shared__ double wsum[4];
     if (lane == 0) wsum[wv] = sum;
     __syncthreads();
@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(256) sum_stage1_kernel(const float* __restrict
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)in[i];
   }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int off = 32; off >= 1; off >>= 1) s += shfl_xor_settled(s, off);
   __shared__ double w[4];
   if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -1119,7 +1119,7 @@ __global__ void __launch_bounds__(64) sum_stage2_kernel(const double* __restrict
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int off = 32; off >= 1; off >>= 1) s += shfl_xor_settled(s, off);
   if (threadIdx.x == 0) out[0] = (float)s;
 }
 
@@ -1128,7 +1128,7 @@ __global__ void __launch_bounds__(1024) sum_stage2_wide_kernel(const double* __r
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) s += partial[i];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int off = 32; off >= 1; off >>= 1) s += shfl_xor_settled(s, off);
   __shared__ double w[16];
   if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
   __syncthreads();

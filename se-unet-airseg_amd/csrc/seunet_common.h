@@ -180,8 +180,43 @@ __device__ __forceinline__ void zero8p(Pack8<float>& k) { k.a = k.b = make_float
 // a cross-lane operand fetched inside the VALU, a couple of cycles) instead of __shfl_xor (ds_bpermute: an LDS round
 // trip of ~100 cycles in a dependent chain).  quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies;
 // row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i) pair up the already reduced quads / octets.
+//
+// DPP and the EXEC mask (found in round 4).  A DPP fetch with bound_ctrl returns 0 for a source lane that is disabled, and the
+// DPP stage looks at EXEC late: where the compiler placed an s_and_saveexec (the `if (cg == 0)` that follows a group sum) right
+// behind the last DPP instruction, the last 16 lanes of the wave occasionally saw the NARROWED mask -- their partner lanes read as
+// 0 and the side value lost half of its channels.  Seen only while a second process kept the chip busy (two ranks on one GPU in the
+// data-parallel tests; scripts/r4_stress3.py: 5 % of launches), never in the sums that are followed by more vector work.  The ISA
+// lists the mirror case (a VALU write of EXEC needs 5 wait states before a DPP), not this one, and the hazard recognizer inserts
+// nothing.  `dpp_settle` makes a value that came through DPP the operand of a plain vector move: the move cannot issue before the
+// DPP instruction has completed, and a scalar write of EXEC behind it is ordered after it by the ordinary interlock.  Every
+// reduction that ends in DPP passes its result through it.
+__device__ __forceinline__ float dpp_settle(float v) {
+  asm volatile("v_mov_b32 %0, %0" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ int dpp_settle(int v) {
+  asm volatile("v_mov_b32 %0, %0" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ unsigned long long dpp_settle(unsigned long long u) {
+  unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(lo), "+v"(hi));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double dpp_settle(double v) {
+  return __builtin_bit_cast(double, dpp_settle(__builtin_bit_cast(unsigned long long, v)));
+}
+// The same holds for the LDS cross-lane instructions (ds_bpermute behind __shfl_*, ds_swizzle): the compiler leaves them in
+// flight across the s_and_saveexec of the `if (lane == 0)` that follows a wave reduction (the s_waitcnt sinks into the branch), and
+// under the same conditions the first-layer block's statistics lost lanes (ec1.conv1.weight / ec1.conv_se.weight off by 1e-4 ..
+// 7e-3 in 1 % of the steps of scripts/r4_stress.py).  Every cross-lane value is settled before it is used: the move needs the
+// result, so the wait for it precedes any change of EXEC.
+template <typename V> __device__ __forceinline__ V shfl_xor_settled(V v, int off) { return dpp_settle(__shfl_xor(v, off, 64)); }
+template <int CTRL> __device__ __forceinline__ int dpp_fetch_bits(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
 template <int CTRL> __device__ __forceinline__ float dpp_fetch(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+  return __builtin_bit_cast(float, dpp_fetch_bits<CTRL>(__builtin_bit_cast(int, v)));
 }
 template <int LPV> __device__ __forceinline__ float group_sum(float v) {
   static_assert(LPV == 1 || LPV == 2 || LPV == 4 || LPV == 8 || LPV == 16, "group_sum: LPV must be 1..16");
@@ -189,17 +224,17 @@ template <int LPV> __device__ __forceinline__ float group_sum(float v) {
   if (LPV >= 4) v += dpp_fetch<0x4E>(v);    // quad_perm [2,3,0,1]
   if (LPV >= 8) v += dpp_fetch<0x141>(v);   // row_half_mirror
   if (LPV >= 16) v += dpp_fetch<0x140>(v);  // row_mirror
-  return v;
+  return LPV >= 2 ? dpp_settle(v) : v;
 }
 // sum over all lanes with the same (lane % LPV): the lanes holding the same channels
 template <int LPV> __device__ __forceinline__ float stride_sum(float v) {
 #pragma unroll
-  for (int off = 32; off >= LPV; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = 32; off >= LPV; off >>= 1) v += shfl_xor_settled(v, off);
   return v;
 }
 template <int LPV> __device__ __forceinline__ double stride_sum_d(double v) {
 #pragma unroll
-  for (int off = 32; off >= LPV; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = 32; off >= LPV; off >>= 1) v += shfl_xor_settled(v, off);
   return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -547,7 +547,7 @@ def test_three_channel_input_takes_the_materialised_x_branch_fp32(A, orc):
     _check_vs_same_choice_f64(orc, m, b, 1, what="in_channel=3:", xtol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
 def test_gradients_are_bitwise_reproducible(A, orc, dtype):
     """Every reduction on the path (InstanceNorm partial sums, parameter-gradient records, weight-gradient slabs, loss
     sums) is summed in a fixed order and nothing uses atomics: two runs of the same step give identical bits."""
@@ -564,6 +564,45 @@ def test_gradients_are_bitwise_reproducible(A, orc, dtype):
     assert runs[0][2].keys() == runs[1][2].keys() and len(runs[0][2]) == 116
     for n in runs[0][2]:
         assert torch.equal(runs[0][2][n], runs[1][2][n]), n
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("batch,size", [(2, (32, 32, 32)), (1, (64, 64, 64)), (1, (40, 48, 56))])
+def test_results_do_not_depend_on_the_prior_contents_of_the_workspace(A, orc, dtype, batch, size, monkeypatch):
+    """The caller owns the workspace and hands it over uninitialised (torch.empty: whatever an earlier step left there).  A step over
+    a workspace, outputs and gradient buffer pre-filled with 0xFF bytes (NaN patterns in bf16 / fp16 / f32 / f64) must give the very
+    bits of a step over zero-filled ones: the library reads no byte that it has not written in the same pass."""
+    import importlib
+    host = importlib.import_module("seunet_amd.SE_UNet")      # (the module; the package attribute of that name is the class)
+    b = orc.synthetic_batch(batch, size, 2, seed=13)
+    x, lab = b["image"].cuda(), b["label"].cuda()
+    runs = []
+    for fill in (0x00, 0xFF):
+        monkeypatch.setattr(host, "_DEBUG_FILL", fill)
+        m = build(A, orc, 2, dtype)
+        e, d = m(x)
+        loss = A.fused_stage_loss(1, e, d, lab)
+        loss.backward()
+        runs.append((loss.detach().clone(), e.detach().clone(), d.detach().clone(),
+                     {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    monkeypatch.setattr(host, "_DEBUG_FILL", None)
+    assert torch.isfinite(runs[1][0]) and torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    bad = [n for n in runs[0][3] if not torch.equal(runs[0][3][n], runs[1][3][n])]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,reps", [("fp32", 300), ("bf16", 400)])
+def test_step_is_bitwise_stable_while_another_process_shares_the_gpu(dtype, reps):
+    """tests/stress_shared_gpu.py: one process repeats a 1 x 2 x 32^3 step while a second one runs steps of another shape on the same
+    GPU; every repetition must reproduce the first bit for bit.  Before round 4's fix (cross-lane results settled before any change
+    of EXEC) 5-8 % of the repetitions differed under exactly these conditions -- the conditions of the two-rank data-parallel tests."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_shared_gpu.py")
+    r = subprocess.run([sys.executable, script, dtype, "1", "32", str(reps)], capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0 and f"{reps} repetitions, 0 differ from the first" in r.stdout, tail
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -761,7 +800,7 @@ def _run_dp_equivalence(A, orc, backend, overlap=False, dtype="fp32", tol=1e-4, 
     assert abs(res[0][1] - float(loss.detach())) < loss_tol and abs(res[1][1] - float(loss.detach())) < loss_tol
     assert res[0][2] and res[1][2], "gradients of a real backward are not one contiguous bucket"
     assert res[0][3] == 1_520_314 - 768
-    worst = 0.0
+    worst, worst_name = 0.0, ""
     for k, p in m.named_parameters():
         if p.grad is None:
             continue
@@ -769,8 +808,10 @@ def _run_dp_equivalence(A, orc, backend, overlap=False, dtype="fp32", tol=1e-4, 
         if k.endswith("conv1.bias"):
             assert float(got.abs().max()) <= 1e-6
             continue
-        worst = max(worst, float((got - ref).norm() / max(float(ref.norm()), 1e-30)))
-    print(f"1 GPU x B=2 vs 2 ranks x B=1 ({backend}, {dtype}, {'overlapped' if overlap else 'serial'}): worst gradient rel-L2 {worst:.2e}")
+        e = float((got - ref).norm() / max(float(ref.norm()), 1e-30))
+        if e > worst:
+            worst, worst_name = e, k
+    print(f"1 GPU x B=2 vs 2 ranks x B=1 ({backend}, {dtype}, {'overlapped' if overlap else 'serial'}): worst gradient rel-L2 {worst:.2e} ({worst_name})")
     assert worst < tol
 
 
@@ -788,12 +829,13 @@ def test_data_parallel_overlapped_exchange_equals_one_rank_batch2_gloo_shared_gp
     _run_dp_equivalence(A, orc, "gloo", overlap=True)
 
 
-# 16-bit storage modes (BASELINE configs[2] is bf16, configs[4] fp16).  The sample-wise kernels give the same bits for a sample
-# whatever the batch it sits in, except the InstanceNorm partial-sum order (a function of the batch size), so 1 x B=2 and 2 x B=1
-# differ by a rounding of the statistics that a 16-bit store then either keeps or amplifies to one unit in the last place:
-# the bound is the storage format's own step (measured on MI355X: see the printed value), far below the mode's distance from
-# float64 (bf16 5e-2, fp16 6e-3) and three orders above what a missing or doubled exchange would give (rel-L2 ~ 1).
-DP_16BIT = [("bf16", 2e-2), ("fp16", 3e-3)]
+# 16-bit storage modes (BASELINE configs[2] is bf16, configs[4] fp16).  The sample-wise kernels give a sample the same bits whatever
+# the batch it sits in (at this size the InstanceNorm partial counts do not depend on the batch either), so 1 x B=2 and 2 x B=1 differ
+# only in the order of the weight-gradient sums: measured on MI355X 1.1e-7 (bf16) and 9.6e-8 (fp16), serial and overlapped alike.
+# The bound is 100 x that: one discrete choice taken differently on one rank costs 1e-3 (which is what this test showed once, 2.5e-3,
+# before the cross-lane / EXEC fix of round 4 -- two ranks sharing a GPU are exactly the condition that exposed it), a missing or
+# doubled exchange costs ~1.
+DP_16BIT = [("bf16", 1e-5), ("fp16", 1e-5)]
 
 
 @pytest.mark.parametrize("overlap", [False, True])
