@@ -142,9 +142,9 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--cpu-size", type=int, default=128)
     ap.add_argument("--dump-kernels", default="", help="write the full per-launch-group timing table (TSV) here")
-    ap.add_argument("--config", default="", choices=["", "window512"],
-                    help="window512: also time BASELINE configs[3] (one 512^3 volume, 128^3 windows, stride 64, 343 windows, forward "
-                         "only) and report it under `window512` (N=1)")
+    ap.add_argument("--config", default="window512", choices=["", "none", "window512"],
+                    help="window512 (default at N=1): also time BASELINE configs[3] (one 512^3 volume, 128^3 windows, stride 64, 343 "
+                         "windows, forward only; ~3 s) and report it under `window512`; none: skip it")
     return ap.parse_args()
 
 
@@ -400,12 +400,14 @@ def main():
             # HBM traffic of that kernel from rocprofv3 PMC passes over THIS command (scripts/pmc_traffic.sh ->
             # profiles/r03_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x2 per the gfx950 note
             # in MI355X_MICROARCH.md)
-            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
+            if not os.path.exists(tpath):
+                tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
             if os.path.exists(tpath) and B == 4 and S == 128 and args.dtype == "bf16" and args.width == 1:
                 t = json.load(open(tpath)).get("kernels", {}).get(tag)
                 if t:
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/r03_traffic.json (rocprofv3 --pmc over bench.py, per launch)"
+                    out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT) + " (rocprofv3 --pmc over bench.py, per launch)"
 
     # ---- SURVEY 8(d)'s metric as stated: forward + loss + backward (+ the gradient all-reduce for N > 1), no optimizer
     if not args.no_secondary and not args.no_optimizer:
@@ -444,9 +446,18 @@ def main():
                 res = A.sliding_window_predict(mw, vol, return_tensor=True)
                 fence()
                 times.append(time.perf_counter() - t0)
+            # 343 windows x the forward byte model (1.51 TB in 16-bit storage, 3.02 TB in fp32) against 8 TB/s, and
+            # the forward FLOPs (216.3 TFLOP) against the dense MFMA peak
+            w_bytes = 343 * MODEL_FWD_BYTES_PER_VOXEL_2B.get(args.width, 2098.0) * (esz / 2) * 128 ** 3
+            w_flops = 343 * (MODEL_FLOP_PER_VOXEL.get(args.width, 901.0e3) / 3.0) * 128 ** 3
             out["window512"] = {"seconds": min(times), "runs": times, "windows": 343, "batch": auto_batch(mw, dev),
                                 "output_voxels_per_s": 512 ** 3 / min(times), "window_voxels_per_s": 343 * 128 ** 3 / min(times),
                                 "dtype": args.dtype, "finite": bool(torch.isfinite(res).all()),
+                                "roofline": {"bound": "hbm", "achieved": w_bytes / min(times) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                             "frac": w_bytes / min(times) / 1e9 / PEAK_HBM_GBS, "model_bytes": w_bytes,
+                                             "mfma_frac": w_flops / min(times) / (PEAK_TFLOPS[args.dtype] * 1e12),
+                                             "what": "whole loop against SURVEY.md 8(d)'s forward byte model x 343 windows (traffic: null, "
+                                                     "a model figure, not a PMC reading)", "traffic": None},
                                 "what": "one 512^3 two-channel volume resident in HBM -> overlap-averaged sigmoid volume (float64) in HBM; "
                                         "decoder-head-only forward per window batch, device-side gather / accumulate / divide"}
             del mw, vol, res

@@ -63,10 +63,11 @@ def oracle_choices(orc, model, image):
     return signs, pools
 
 
-def forced_step(orc, batch, stage, signs, pools, slope=0.01, width_mult=1):
+def forced_step(orc, batch, stage, signs, pools, slope=0.01, width_mult=1, drops=None):
     """float64 oracle forward + stage loss + backward with the given choices imposed.  Returns (model with .grad, pred0,
-    pred1, loss, number of sign choices that differ from float64's own, number of pool choices that differ)."""
-    o = orc.build_oracle(batch["image"].shape[1], 1, width_mult, seed=0).double()
+    pred1, loss, number of sign choices that differ from float64's own, number of pool choices that differ).
+    ``drops``: the two DropLayer scale tensors of a train-mode step (injected into the oracle like into the HIP path)."""
+    o = orc.build_oracle(batch["image"].shape[1], 1, width_mult, seed=0, train=drops is not None).double()
     calls = {"lrelu": 0, "pool": 0, "sign_flips": 0, "pool_flips": 0}
     real_lrelu, real_pool = F.leaky_relu, F.max_pool3d
 
@@ -91,7 +92,10 @@ def forced_step(orc, batch, stage, signs, pools, slope=0.01, width_mult=1):
         return t.flatten(2).gather(2, idx.flatten(2)).reshape(n, c, *idx.shape[2:])
     orc.F.leaky_relu, orc.F.max_pool3d = lrelu, pool
     try:
-        pe, pd = o(batch["image"].double())
+        if drops is None:
+            pe, pd = o(batch["image"].double())
+        else:
+            pe, pd = o(batch["image"].double(), drops[0].double(), drops[1].double())
     finally:
         orc.F.leaky_relu, orc.F.max_pool3d = real_lrelu, real_pool
     assert calls["lrelu"] == len(LRELU_ORDER) and calls["pool"] == len(POOL_ORDER), calls

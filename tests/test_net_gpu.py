@@ -102,21 +102,22 @@ def _rel_errors(model, ref64):
 
 
 def _check_grad_noise(err, ref_noise):
-    """HIP-vs-float64 gradient errors must sit in the same noise band as the fp32 reference's own distance from its
-    float64 run on the same case (flip noise scales with 1/sqrt(#elements), so the band is case dependent).  Bands are
-    ~2x what was measured on MI355X (2x2x32^3, stage 1: median 4.4e-4, p90 2.0e-3, worst 2.95e-3 against the fp32
-    reference's own 3.5e-6 / 1.8e-3 / 2.5e-3; width x2: 7.0e-4 / 1.7e-3 / 2.9e-3 against 9.3e-4 / 2.1e-3 / 3.9e-3), so
-    at 1x2x40^3: 6.4e-4 / 4.5e-3 / 8.8e-3 against 3.7e-4 / 2.9e-3 / 4.9e-3), so a 3x regression fails:
-    median <= max(9e-4, 2 x ref), 90th percentile <= max(4e-3, 2.5 x ref), worst <= max(6e-3, 3 x ref)."""
+    """Coarse companion of the same-choice gate below: the HIP path's distance from the PLAIN float64 oracle, next to the fp32
+    reference's own distance from it on the same case.  Both are flip noise -- which handful of LeakyReLU signs / arg-maxes the
+    fp32 forward takes differently from float64, and where they sit (measured on MI355X at 2 x 2 x 32^3, stage 1: HIP median 4.4e-4,
+    p90 2.1e-3, worst 3.2e-3; fp32 reference 3.5e-6 / 1.8e-3 / 2.5e-3; in train mode one tensor reached 6.4e-3 with every tensor
+    within 9e-6 of float64 under the same choices) -- so this is only a tripwire for SYSTEMATIC error (f32 instead of f64
+    InstanceNorm sums shows up as a median of ~1e-2): median <= max(2e-3, 4 x ref), worst <= max(2e-2, 6 x ref).  The arithmetic
+    gate is _check_vs_same_choice_f64 (3e-5 per tensor), which every caller of this function also runs."""
     v, r = np.array(list(err.values())), np.array(list(ref_noise.values()))
     stats = (float(np.median(v)), float(np.percentile(v, 90)), float(v.max()))
     ref = (float(np.median(r)), float(np.percentile(r, 90)), float(r.max()))
     print("gradient rel-L2 vs f64 (median, p90, max): HIP %.2e %.2e %.2e | fp32 reference %.2e %.2e %.2e" % (stats + ref))
-    assert stats[0] <= max(9e-4, 2 * ref[0]) and stats[1] <= max(4e-3, 2.5 * ref[1]) and stats[2] <= max(6e-3, 3 * ref[2]), \
+    assert stats[0] <= max(2e-3, 4 * ref[0]) and stats[2] <= max(2e-2, 6 * ref[2]), \
         (stats, ref, sorted(err.items(), key=lambda kv: -kv[1])[:6])
 
 
-def _check_vs_same_choice_f64(orc, m, b, stage, width_mult=1, tol=3e-5, what="", xtol=None, max_flip_frac=2e-6):
+def _check_vs_same_choice_f64(orc, m, b, stage, width_mult=1, tol=3e-5, what="", xtol=None, max_flip_frac=2e-6, drops=None):
     """The flip-free network-level gradient gate (tests/forced_oracle.py): the float64 oracle is run with the LeakyReLU signs and
     max-pool arg-maxes that THIS forward of the HIP path took (read back from its workspace; the raw-input branches x33 / x63 /
     x93, which leave no tensor when in_channel <= 2, are recomputed by the device function the aggregation epilogue uses), and
@@ -133,7 +134,7 @@ def _check_vs_same_choice_f64(orc, m, b, stage, width_mult=1, tol=3e-5, what="",
     import forced_oracle as FO
     _, _, inter = m.forward_with_intermediates(b["image"].cuda(), FO.LRELU_ORDER)
     signs, pools = FO.path_choices(inter)
-    of, fe, fd, lf, nsf, npf = FO.forced_step(orc, b, stage, signs, pools, width_mult=width_mult)
+    of, fe, fd, lf, nsf, npf = FO.forced_step(orc, b, stage, signs, pools, width_mult=width_mult, drops=drops)
     err = _rel_errors(m, of)
     v = np.array(list(err.values()))
     choices = sum(int(t.numel()) for t in signs.values()) + sum(int(t.numel()) for t in pools.values())
@@ -634,7 +635,16 @@ def test_train_mode_forward_backward_injected_drop_fp32(A, orc, stage):
     loss = A.fused_stage_loss(stage, ge, gd, c["label"], c["weight"], c["skel"])
     loss.backward()
     assert abs(float(loss.detach()) - float(l64.detach())) < 1e-5
-    _check_grad_noise(_rel_errors(m, o64), _rel_errors(o32, o64))
+    # Gradients: against float64 with this forward's own discrete choices AND the same injected drop scales, every tensor to
+    # rounding (measured 8.7e-6 worst).  The distance from the plain float64 run is printed only: it measures where the handful of
+    # differing LeakyReLU signs fell (round 4: four of 15 million moved dc42.conv1.weight to 6.4e-3, with every tensor within 9e-6 of
+    # float64 under the same choices).
+    err, ref = _rel_errors(m, o64), _rel_errors(o32, o64)
+    print("train mode, plain float64 (flip noise): HIP median %.2e max %.2e | fp32 oracle median %.2e max %.2e" %
+          (np.median(list(err.values())), max(err.values()), np.median(list(ref.values())), max(ref.values())))
+    was_training = m.training
+    _check_vs_same_choice_f64(orc, m.eval(), b, stage, what=f"train mode stage {stage}:", drops=(d1, d2))   # (eval(): the diagnostic forward reads block tensors, which do not depend on DropLayer)
+    m.train(was_training)
     # a dropped side map contributes nothing: the head weight of a channel dropped in EVERY sample gets a zero gradient
     dead1 = (d1.reshape(2, 24) == 0).all(0)
     if bool(dead1.any()):
