@@ -81,6 +81,17 @@ __device__ __forceinline__ void stream_dma16(const void* gsrc, unsigned lds_dst)
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// The same through a buffer descriptor (round 4): the 16 bytes of a lane come from base + soffset + voffset, and a lane whose
+// voffset lies beyond num_records writes ZEROS into the LDS (probed on gfx950: scripts/probes/blds_oob.hip).  So the padding of a
+// plane image needs neither a zero page nor a per-lane pointer select nor a 64-bit address: the lane's offset inside a plane is
+// a constant (0xFFFFFFFF for padding voxels), the plane's offset inside the sample a scalar, a plane outside the volume a
+// descriptor of zero records.  One vector register, no vector arithmetic per DMA instruction.
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_dma16_buf(unsigned voff, u32x4s rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
 template <int N> __device__ __forceinline__ void stream_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // FWD: bias + InstanceNorm partial sums (forward); !FWD: data gradient, optionally accumulating into the destination (DACC)
@@ -128,17 +139,25 @@ conv_stream_kernel(StreamArgs a) {
     doff[it] = ok ? (unsigned)(((y * a.W + x) * CIN + p * 8) * (int)sizeof(T)) : 0xFFFFFFFFu;
     dlds[it] = (unsigned)(p * PS + gi * 1024);
   }
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
-  // plane of step s -> ring slot `slot` (= s % Geo::RING).  The plane-level part (validity, 64-bit plane base, LDS slot base) is
-  // computed once per step (`plane_of`) and handed to the items: they sit in different scheduling regions, so the compiler
-  // recomputed it for each of them, and these loops are bound by instruction issue
-  struct PlaneRef { const unsigned char* base; unsigned lds; bool ok; };
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;     // (old destination rows only)
+  // source descriptor of this sample: base (scalar registers), num_records = the sample's bytes (0 for a plane outside the volume)
+  unsigned src_lo, src_hi;
+  {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(src_n);
+    src_lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    src_hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xFFFFu;
+  }
+  const unsigned sample_bytes = (unsigned)((long long)a.D * plane_bytes);      // < 2^32 (checked by the launcher)
+  // plane of step s -> ring slot `slot` (= s % Geo::RING).  The plane-level part (validity, offset of the plane inside the sample,
+  // LDS slot base) is computed once per step (`plane_of`) and handed to the items
+  struct PlaneRef { unsigned soff; unsigned nrec; unsigned lds; };
   auto plane_of = [&](int s, int slot) __attribute__((always_inline)) -> PlaneRef {
     PlaneRef r;
     const int pl = q0 - 1 + s;                                      // plane index in the parity class
     const int z = pz + DIL * pl;
-    r.ok = pl >= 0 && z < a.D && s < nsteps;                        // wave-uniform
-    r.base = src_n + (long long)(r.ok ? z : 0) * plane_bytes;
+    const bool ok = pl >= 0 && z < a.D && s < nsteps;               // wave-uniform
+    r.soff = (unsigned)((long long)(ok ? z : 0) * plane_bytes);
+    r.nrec = ok ? sample_bytes : 0u;
     r.lds = lds_base + (unsigned)(slot * PLANE);
     return r;
   };
@@ -146,10 +165,11 @@ conv_stream_kernel(StreamArgs a) {
     constexpr int it = decltype(it_c)::value;
     if constexpr (it < ITEMS) {
       // every wave issues exactly ITEMS instructions per plane (the vmcnt arithmetic of the march counts on it): an item
-      // number beyond the plane's NP * G pieces copies the zero page into the dump area
+      // number beyond the plane's NP * G pieces reads nothing (zero records) into the dump area
       const bool real = wave + ST_NW * it < NP * G;                 // wave-uniform
-      const unsigned char* gp = (r.ok && real && doff[it] != 0xFFFFFFFFu) ? r.base + doff[it] : zero_page;
-      stream_dma16(gp, real ? r.lds + dlds[it] : lds_base + (unsigned)(Geo::RING * PLANE));
+      u32x4s rs;
+      rs.x = src_lo; rs.y = src_hi; rs.z = real ? r.nrec : 0u; rs.w = 0x00020000u;
+      stream_dma16_buf(doff[it], rs, r.soff, real ? r.lds + dlds[it] : lds_base + (unsigned)(Geo::RING * PLANE));
     }
   };
   auto dma_plane = [&](int s, int slot) __attribute__((always_inline)) {
@@ -224,10 +244,25 @@ conv_stream_kernel(StreamArgs a) {
 #pragma unroll
   for (int e = 0; e < SR; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
-  // destination: buffer descriptor over this sample (range-checked 32-bit offsets; padding voxels use an offset beyond it)
+  // destination: buffer descriptor over this sample (range-checked 32-bit offsets).  The lane's part of a store offset -- row y
+  // of this wave, voxel x, run of 4 channels; 0x80000000 = outside the volume / beyond the last channel: dropped by the range
+  // check -- is a constant of the march (one register per store instruction), the plane's part a scalar, a plane outside the march
+  // a descriptor of zero records: no vector arithmetic per store (round 4; the marching kernel's scheme)
   const long long dst_sample = (long long)a.D * a.H * a.W * a.dstC * (long long)sizeof(T);
-  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<unsigned char*>(a.dst) + (long long)n * dst_sample, 0, (int)dst_sample, 0x00020000);
+  unsigned char* const dst_n = reinterpret_cast<unsigned char*>(a.dst) + (long long)n * dst_sample;
+  const int dst_plane = __builtin_amdgcn_readfirstlane(a.H * a.W * a.dstC * (int)sizeof(T));
+  bool okl[NBX];
+  unsigned lofs[NBX][ACCR / 4];
+#pragma unroll
+  for (int b = 0; b < NBX; ++b) {
+    const int y = y0 + ra, x = x0 + b * NB + fn;
+    okl[b] = y < a.H && x < a.W;
+#pragma unroll
+    for (int pc = 0; pc < ACCR / 4; ++pc) {
+      const int c0 = chan(4 * pc);
+      lofs[b][pc] = (okl[b] && c0 < a.cout) ? (unsigned)(((y * a.W + x) * a.dstC + c0) * (int)sizeof(T)) : 0x80000000u;
+    }
+  }
 
   // ---- one step: input plane of step s (ring slot `slot`) -> accumulators; PH = s % 3 ----
   // The fragments of input row ri + 1 are requested before the MFMAs of row ri issue (two register sets), and the prefetch
@@ -298,40 +333,34 @@ conv_stream_kernel(StreamArgs a) {
     const int q = q0 + s - 2;                                       // parity-class plane index
     const int z = pz + DIL * q;
     const bool zok = q >= q0 && q < q1;                             // wave-uniform
-    {
-      const int y = y0 + ra;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst_n, 0, zok ? (int)dst_sample : 0, 0x00020000);
+    const int soff = __builtin_amdgcn_readfirstlane(zok ? z * dst_plane : 0);
 #pragma unroll
-      for (int b = 0; b < NBX; ++b) {
-        const int x = x0 + b * NB + fn;
-        const bool ok = zok && y < a.H && x < a.W;
-        float v[ACCR];
+    for (int b = 0; b < NBX; ++b) {
+      float v[ACCR];
 #pragma unroll
-        for (int e = 0; e < ACCR; ++e) v[e] = acc[ai][b][e];       // (bias included: it was the C operand of the set's first MFMA)
-        if constexpr (FWD) {
-          if (ok) {                      // (a.stats == nullptr: the sums are simply never stored)
+      for (int e = 0; e < ACCR; ++e) v[e] = acc[ai][b][e];       // (bias included: it was the C operand of the set's first MFMA)
+      if constexpr (FWD) {
+        if (zok && okl[b]) {             // (a.stats == nullptr: the sums are simply never stored)
 #pragma unroll
-            for (int e = 0; e < ACCR; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
-          }
+          for (int e = 0; e < ACCR; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
         }
-        const unsigned vox = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
-        // runs of 4 consecutive channels -> 8-byte pieces
+      }
+      // runs of 4 consecutive channels -> 8-byte pieces
 #pragma unroll
-        for (int pc = 0; pc < ACCR / 4; ++pc) {
+      for (int pc = 0; pc < ACCR / 4; ++pc) {
+        float w4[4] = {v[4 * pc], v[4 * pc + 1], v[4 * pc + 2], v[4 * pc + 3]};
+        if constexpr (DACC) {
           const int c0 = chan(4 * pc);
-          const bool cok = ok && c0 < a.cout;
-          const unsigned off = cok ? (vox * (unsigned)a.dstC + (unsigned)c0) * (unsigned)sizeof(T) : 0x80000000u;   // beyond the sample: dropped
-          float w4[4] = {v[4 * pc], v[4 * pc + 1], v[4 * pc + 2], v[4 * pc + 3]};
-          if constexpr (DACC) {
-            const u32x2s o = *reinterpret_cast<const u32x2s*>(smem + Geo::OLD + (slot * ST_NW + wave) * Geo::OLDI * 1024 +
-                                                               ((b * NB + fn) * a.dstC + c0) * (int)sizeof(T));
-            w4[0] += unpack_lo<T>(o.x); w4[1] += unpack_hi<T>(o.x);
-            w4[2] += unpack_lo<T>(o.y); w4[3] += unpack_hi<T>(o.y);
-          }
-          u32x2s u;
-          u.x = pack2<T>(w4[0], w4[1]);
-          u.y = pack2<T>(w4[2], w4[3]);
-          __builtin_amdgcn_raw_buffer_store_b64(u, rd, off, 0, 0);
+          const u32x2s o = *reinterpret_cast<const u32x2s*>(smem + Geo::OLD + (slot * ST_NW + wave) * Geo::OLDI * 1024 +
+                                                             ((b * NB + fn) * a.dstC + c0) * (int)sizeof(T));
+          w4[0] += unpack_lo<T>(o.x); w4[1] += unpack_hi<T>(o.x);
+          w4[2] += unpack_lo<T>(o.y); w4[3] += unpack_hi<T>(o.y);
         }
+        u32x2s u;
+        u.x = pack2<T>(w4[0], w4[1]);
+        u.y = pack2<T>(w4[2], w4[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(u, rd, lofs[b][pc], soff, 0);
       }
     }
   };
@@ -505,7 +534,8 @@ int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const voi
   const int var = stream_variant(dtype, 27, dil, src_c, dst_c);
   SEUNET_CHECK(var != 0, "conv_stream: unsupported shape (%d -> %d channels, dilation %d, dtype %d)", src_c, dst_c, dil, dtype);
   SEUNET_CHECK(src && wpack && dst && dst_c % 8 == 0, "conv_stream: bad argument");
-  SEUNET_CHECK((long long)d.vox() * dst_c * 2 < (1LL << 31) && (long long)d.H * d.W * src_c * 2 < (1LL << 31),
+  SEUNET_CHECK((long long)d.vox() * dst_c * 2 < (1LL << 31) && (long long)d.H * d.W * src_c * 2 < (1LL << 31) &&
+               (long long)d.vox() * src_c * 2 < (1LL << 32),
                "conv_stream: one sample exceeds the 32-bit offsets of this kernel");
   StreamArgs a{};
   a.src = src; a.wpack = wpack; a.bias = bias; a.dst = dst; a.dstC = dst_c; a.dacc = dst_accumulate; a.cout = dst_c;
