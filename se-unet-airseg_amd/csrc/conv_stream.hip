@@ -53,7 +53,10 @@ struct StreamArgs {
   int nyb, nxb, nzseg, zsteps;      // patches, z segments (per parity class), output planes per segment
 };
 
-static constexpr int ST_TY = 8, ST_TX = 32, ST_NW = 8;   // 8 waves: one output row each, two waves per SIMD
+#ifndef SEUNET_STREAM_ROWS
+#define SEUNET_STREAM_ROWS 8
+#endif
+static constexpr int ST_TY = SEUNET_STREAM_ROWS, ST_TX = 32, ST_NW = SEUNET_STREAM_ROWS;   // 8 waves: one output row each, two waves per SIMD
 
 template <int CIN, int COUTP, bool XFOLD, int DIL, bool DACC = false> struct StreamGeo {
   static constexpr int NP = CIN / 8;
@@ -96,7 +99,7 @@ template <int N> __device__ __forceinline__ void stream_wait_vm() { asm volatile
 
 // FWD: bias + InstanceNorm partial sums (forward); !FWD: data gradient, optionally accumulating into the destination (DACC)
 template <typename T, int CIN, int COUTP, bool XFOLD, int DIL, bool FWD, bool DACC>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(ST_NW * 64, 2)
 conv_stream_kernel(StreamArgs a) {
   using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL, DACC>;
   constexpr int NP = Geo::NP, HX = Geo::HX, HY = Geo::HY, NVP = Geo::NVP, G = Geo::G, PS = Geo::PS, PLANE = Geo::PLANE;
