@@ -311,7 +311,9 @@ int seunet_net_param_count(const seunet_net_desc* desc);
 int seunet_net_param_info(const seunet_net_desc* desc, int index, char* name, int name_cap, int* shape5, int* ndim);
 size_t seunet_net_workspace_bytes(const seunet_net_desc* desc);
 /* params: seunet_net_param_count device pointers in registry order.  x: NCDHW f32.  drop1/drop2: DropLayer
- * scale tensors [batch][24] / [batch][12] (NULL = eval mode identity).  pred0/pred1: [batch][1][d][h][w] f32 logits.
+ * scale tensors [batch][24] / [batch][12] (NULL = eval mode identity).  pred0/pred1: [batch][n_classes][d][h][w] f32 logits
+ * (n_classes 1 .. 8; SE_UNet.py:100,150-151.  Every reference caller uses 1, which keeps the fused head form; more classes run
+ * the heads on a general path that materialises the 2-channel side maps, csrc/classes.hip).
  * The workspace keeps everything the backward pass needs; pass the same buffer to seunet_net_backward.
  * pred0 == NULL: inference form (prediction.py:102-103 keeps only the decoder head's output): the encoder head, the side convs of
  * the twelve encoder blocks and their level maps are not evaluated; pred1 is bit-identical; no backward pass may follow. */

@@ -14,6 +14,9 @@ The whole forward (and the whole backward) is ONE call into the library
 (``seunet_net_forward`` / ``seunet_net_backward``): the graph walk, workspace layout and all kernel
 launches are native.  There is no PyTorch or CPU fallback: a CPU tensor or a missing ``.so`` raises.
 
+``n_classes > 1`` (SE_UNet.py:100,150-151; no reference caller uses it) runs the heads on a general path (csrc/classes.hip: side
+maps materialised, level maps per class) -- same results, more bytes than the fused single-class form.
+
 Extras over the reference, all defaulting to its behaviour: ``width_mult``,
 ``negative_slope`` (D1), ``act_dtype`` ('bf16' performance mode / 'fp16' / 'fp32' 1e-3-parity mode) and a
 device-agnostic ``DropLayer`` with the reference's CPU-generator RNG order (Q6).
@@ -186,8 +189,8 @@ class _SEUNetFunction(torch.autograd.Function):
             if ws_bytes == 0:
                 raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
             ws = _fresh(ws_bytes, torch.uint8, x.device)
-            pred0 = _fresh((b, 1, d, h, w), torch.float32, x.device)
-            pred1 = _fresh((b, 1, d, h, w), torch.float32, x.device)
+            pred0 = _fresh((b, meta["n_classes"], d, h, w), torch.float32, x.device)
+            pred1 = _fresh((b, meta["n_classes"], d, h, w), torch.float32, x.device)
             plist = [p.detach().contiguous() for p in params]
             for p in plist:
                 if p.device != x.device:
@@ -212,7 +215,7 @@ class _SEUNetFunction(torch.autograd.Function):
                                "back-propagated separately) is not supported -- sum the losses and call backward once")
         lib = _lib.load()
         dev = ctx.ws.device
-        shape = (ctx.desc.batch, 1, ctx.desc.d, ctx.desc.h, ctx.desc.w)
+        shape = (ctx.desc.batch, ctx.desc.n_classes, ctx.desc.d, ctx.desc.h, ctx.desc.w)
         with torch.cuda.device(dev):
             g0 = torch.zeros(shape, dtype=torch.float32, device=dev) if g0 is None else g0.contiguous().float()
             g1 = torch.zeros(shape, dtype=torch.float32, device=dev) if g1 is None else g1.contiguous().float()
@@ -327,7 +330,7 @@ class SE_UNet(nn.Module):
         with torch.cuda.device(x.device):
             nbytes = lib.seunet_net_workspace_bytes(C.byref(desc))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            pred0 = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
+            pred0 = torch.empty((b, self.n_classes, d, h, w), dtype=torch.float32, device=x.device)
             pred1 = torch.empty_like(pred0)
             plist = [p.detach().contiguous() for p in self.parameters()]
             parr = _lib.ptr_array(plist)
@@ -357,7 +360,7 @@ class SE_UNet(nn.Module):
     @torch.no_grad()
     def predict_logits(self, x, out: Optional[torch.Tensor] = None):
         """Inference form of the forward (prediction.py:102-103 ``p0, p = model(x)`` keeps only ``p``): the decoder head's logits
-        (B, 1, D, H, W), bit-identical to ``forward(x)[1]``; the encoder head, its twelve side convs and level maps are not
+        (B, n_classes, D, H, W), bit-identical to ``forward(x)[1]``; the encoder head, its twelve side convs and level maps are not
         evaluated (``seunet_net_forward`` with pred0 = NULL).  No autograd graph.  The workspace is a per-shape arena owned by
         the module and reused by every call (not a fresh 3-12 GB allocation per forward); ``release_arena()`` frees it."""
         if not x.is_cuda:
@@ -385,7 +388,7 @@ class SE_UNet(nn.Module):
                 self._arena.clear()         # one shape at a time: a window loop uses one (plus a ragged last batch)
                 arena = self._arena[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             if out is None:
-                out = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=x.device)
+                out = torch.empty((b, self.n_classes, d, h, w), dtype=torch.float32, device=x.device)
             plist = [p.detach().contiguous() for p in self.parameters()]
             _lib.check(lib.seunet_net_forward(C.byref(desc), _lib.ptr_array(plist), x.data_ptr(), _lib.ptr(d1), _lib.ptr(d2), None,
                                               out.data_ptr(), arena.data_ptr(), arena.numel(), _lib.stream_ptr()), "net_forward")
@@ -460,7 +463,7 @@ class CapturedForward:
                 raise RuntimeError("libseunet_hip net_workspace_bytes: " + _lib.last_error())
             self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
             self.x = torch.zeros((batch, model.in_channel, d, h, w), dtype=torch.float32, device=dev)
-            self.pred0 = torch.empty((batch, 1, d, h, w), dtype=torch.float32, device=dev)
+            self.pred0 = torch.empty((batch, model.n_classes, d, h, w), dtype=torch.float32, device=dev)
             self.pred1 = torch.empty_like(self.pred0)
             self.drop1 = torch.ones((batch, 24), dtype=torch.float32, device=dev)
             self.drop2 = torch.ones((batch, 12), dtype=torch.float32, device=dev)

@@ -142,6 +142,7 @@ struct OpRes {
   bool stream_f = false, stream_d = false, stream_w = false;   // forward / data gradient / weight gradient on the streaming kernels
   bool march_f = false, march_d = false;                       // forward / data gradient on the marching kernel (conv_march.hip)
   size_t pool_idx = 0; bool has_pool_idx = false;              // OP_POOL behind a fused aggregation block: arg-max words of the forward
+  size_t side = 0;                                             // n_classes > 1: the block's 2-channel side map, f32 [N][V][2] (classes.hip)
 };
 
 struct Plan {
@@ -153,6 +154,7 @@ struct Plan {
   OpRes op[kNumOps];
   size_t lvl[2][4], glvl[2][4];
   size_t stats, stats2, pgrad, m1, m2, m1b, m2b, wgrad_ws, head_tmp, gx, gx_bytes = 0, xwp = 0, xmom = 0;
+  size_t gside = 0, cls_part = 0, cls_bias = 0;                // n_classes > 1: side-map gradient of one block, head-gradient records, per-(sample, class) bias sums
   // x-branches (x33 / x63 / x93) recomputed from the <= 2-channel input instead of materialised (csrc/epilogue.hip, XR)
   bool fuse_x = false;
   bool use_stream = true;
@@ -167,7 +169,7 @@ struct Plan {
   int init(const seunet_net_desc& desc) {
     d = desc;
     SEUNET_CHECK(d.batch >= 1 && d.in_channel >= 1 && d.in_channel <= 8, "net: batch/in_channel out of range");
-    SEUNET_CHECK(d.n_classes == 1, "net: n_classes=%d is not implemented in the HIP path (reference callers use 1)", d.n_classes);
+    SEUNET_CHECK(d.n_classes >= 1 && d.n_classes <= class_max(), "net: n_classes=%d out of range (1 .. %d)", d.n_classes, class_max());
     SEUNET_CHECK(d.d % 8 == 0 && d.h % 8 == 0 && d.w % 8 == 0 && d.d >= 8 && d.h >= 8 && d.w >= 8,
                  "net: spatial extents (%d,%d,%d) must be multiples of 8", d.d, d.h, d.w);
     SEUNET_CHECK(d.width_mult == 1 || d.width_mult == 2, "net: width_mult %d unsupported (1 or 2)", d.width_mult);
@@ -255,13 +257,19 @@ struct Plan {
       }
       slots_max = std::max(slots_max, std::max(std::max(conv_stats_tiles(dims[lv], 27, 1), conv_stats_tiles(dims[lv], 27, 2)), epi_partials(dims[lv])));
       cmax = std::max(cmax, r.cout);
+      if (d.n_classes > 1 && o.kind == OP_GATED) r.side = take((size_t)d.batch * dims[lv].vox() * 2 * 4);
     }
     stat_slots_max = slots_max;
     for (int h = 0; h < 2; ++h)
       for (int l = 0; l < 4; ++l) {
-        lvl[h][l] = take((size_t)d.batch * dims[l].vox() * 4);
-        glvl[h][l] = take((size_t)d.batch * dims[l].vox() * 4);
+        lvl[h][l] = take((size_t)d.n_classes * d.batch * dims[l].vox() * 4);       // [class][N][V]
+        glvl[h][l] = take((size_t)d.n_classes * d.batch * dims[l].vox() * 4);
       }
+    if (d.n_classes > 1) {
+      gside = take((size_t)d.batch * dims[0].vox() * 2 * 4);
+      cls_part = take((size_t)d.batch * 256 * 2 * d.n_classes * 8);
+      cls_bias = take((size_t)d.batch * d.n_classes * 4);
+    }
     const size_t stat_bytes = (size_t)d.batch * slots_max * cmax * 2 * 8;   // f32 forward / f64 backward partials
     stats = take(stat_bytes);
     stats2 = take(stat_bytes);
@@ -365,6 +373,11 @@ struct Exec {
     const int lv = kT[o.dst].level;
     h.side_out = nullptr;
     if (o.head == 0 && skip_enc_head) return h;     // (no level map: the epilogue skips the side conv altogether)
+    if (p.d.n_classes > 1) {                        // general head path (classes.hip): the epilogue leaves the side map
+      h.side_out = fat(p.op[&o - kOps].side);
+      h.level_accumulate = first_of_level ? 0 : 1;    // (consumed by launch_side_to_level)
+      return h;
+    }
     h.level_map = fat(p.lvl[o.head][lv]);
     h.level_accumulate = first_of_level ? 0 : 1;
     h.head_w = (o.head == 0 ? P("dc0_0.weight") : P("dc0_1.weight")) + 2 * o.m;
@@ -438,6 +451,12 @@ struct Exec {
         mark("epi_fwd:" + n);
         if (int e = launch_sse_fwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), at(p.feat[o.dst]), hd,
                                    p.dims[lv], s)) return e;
+        if (p.d.n_classes > 1 && hd.side_out != nullptr) {
+          const float* dr = o.head == 0 ? drop1 : drop2;
+          if (int e = launch_side_to_level(fat(r.side), (o.head == 0 ? P("dc0_0.weight") : P("dc0_1.weight")) + 2 * o.m, o.head == 0 ? 24 : 12,
+                                           dr ? dr + 2 * o.m : nullptr, o.head == 0 ? 24 : 12, p.d.n_classes, fat(p.lvl[o.head][lv]),
+                                           hd.level_accumulate, p.dims[lv], s)) return e;
+        }
       } else {  // OP_CAT
         const int lv = kT[o.dst].level;
         if (int e = conv_and_stats(n, 1, 1, srcs(o), r.cin, P(n + ".conv1.weight"), nullptr, r.wp_f, r.raw, r.cout, r.mean,
@@ -478,6 +497,23 @@ struct Exec {
     const float* enc[4] = {fat(p.lvl[0][0]), fat(p.lvl[0][1]), fat(p.lvl[0][2]), fat(p.lvl[0][3])};
     const float* dec[3] = {fat(p.lvl[1][0]), fat(p.lvl[1][1]), fat(p.lvl[1][2])};
     mark("head_fwd");
+    if (p.d.n_classes > 1) {       // once per (sample, class): level maps [class][N][V], logits (N, K, D, H, W)
+      const int K = p.d.n_classes, N = p.d.batch;
+      const Dims d1{1, p.dims[0].D, p.dims[0].H, p.dims[0].W};
+      for (int hd = 0; hd < 2; ++hd) {
+        float* pred = hd == 0 ? pred0 : pred1;
+        if (pred == nullptr) continue;
+        const int nl = hd == 0 ? 4 : 3;
+        for (int n = 0; n < N; ++n)
+          for (int c = 0; c < K; ++c) {
+            const float* lm[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int l = 0; l < nl; ++l) lm[l] = fat(p.lvl[hd][l]) + ((size_t)c * N + n) * p.dims[l].vox();
+            if (int e = launch_head_fwd(lm, nl, (hd == 0 ? P("dc0_0.bias") : P("dc0_1.bias")) + c, pred + ((size_t)n * K + c) * d1.vox(), d1, s)) return e;
+          }
+      }
+      mark("outside");
+      return 0;
+    }
     if (!skip_enc_head)
       if (int e = launch_head_fwd(enc, 4, P("dc0_0.bias"), pred0, p.dims[0], s)) return e;
     if (int e = launch_head_fwd(dec, 3, P("dc0_1.bias"), pred1, p.dims[0], s)) return e;
@@ -538,8 +574,25 @@ struct Exec {
       mark("head_bwd");
       float* ge[4] = {nullptr, fat(p.glvl[0][1]), fat(p.glvl[0][2]), fat(p.glvl[0][3])};
       float* gd[4] = {nullptr, fat(p.glvl[1][1]), fat(p.glvl[1][2]), nullptr};
+      if (p.d.n_classes > 1) {     // once per (sample, class); the bias gradient of a class = its per-sample sums added up
+        const int K = p.d.n_classes, N = p.d.batch;
+        const Dims d1{1, p.dims[0].D, p.dims[0].H, p.dims[0].W};
+        for (int hd = 0; hd < 2; ++hd) {
+          const float* gp = hd == 0 ? g_pred0 : g_pred1;
+          const int nl = hd == 0 ? 4 : 3;
+          for (int n = 0; n < N; ++n)
+            for (int c = 0; c < K; ++c) {
+              float* gl[4] = {nullptr, nullptr, nullptr, nullptr};
+              for (int l = 1; l < nl; ++l) gl[l] = fat(p.glvl[hd][l]) + ((size_t)c * N + n) * p.dims[l].vox();
+              if (int e = launch_head_bwd(gp + ((size_t)n * K + c) * d1.vox(), gl, nl, fat(p.head_tmp), fat(p.cls_bias) + n * K + c, d1, s)) return e;
+            }
+          if (float* gb = grads[find_param(reg, hd == 0 ? "dc0_0.bias" : "dc0_1.bias")])
+            if (int e = launch_class_bias_grad(fat(p.cls_bias), N, K, gb, s)) return e;
+        }
+      } else {
       if (int e = launch_head_bwd(g_pred0, ge, 4, fat(p.head_tmp), grads[find_param(reg, "dc0_0.bias")], p.dims[0], s)) return e;
       if (int e = launch_head_bwd(g_pred1, gd, 3, fat(p.head_tmp), grads[find_param(reg, "dc0_1.bias")], p.dims[0], s)) return e;
+      }
     }
     std::vector<float*> zero_ptrs;
     std::vector<int> zero_counts;
@@ -589,12 +642,29 @@ struct Exec {
         g.g_e = written[o.dst] ? at(p.grad[o.dst]) : nullptr;
         g.g_side = nullptr;
         g.g_level = lv == 0 ? (o.head == 0 ? g_pred0 : g_pred1) : fat(p.glvl[o.head][lv]);
-        const SseHead hd = sse_head(o, drop1, drop2, false);
+        SseHead hd = sse_head(o, drop1, drop2, false);
+        float* g_head = grads[find_param(reg, o.head == 0 ? "dc0_0.weight" : "dc0_1.weight")];
+        if (p.d.n_classes > 1) {
+          // general head path: the K level-map gradients of this level folded into the gradient of the block's side map (and the
+          // head-weight gradient summed on the way); the block's passes then take g_side
+          const int K = p.d.n_classes;
+          const float* dr = o.head == 0 ? drop1 : drop2;
+          const long long V = dm.vox();
+          const float* glev = g.g_level;
+          const long long cstride = lv == 0 ? V : (long long)dm.N * V, nstride = lv == 0 ? (long long)K * V : V;
+          mark("epi_bwd:" + n);
+          if (int e = launch_level_to_side_grad(glev, cstride, nstride, fat(r.side), (o.head == 0 ? P("dc0_0.weight") : P("dc0_1.weight")) + 2 * o.m,
+                                                o.head == 0 ? 24 : 12, dr ? dr + 2 * o.m : nullptr, o.head == 0 ? 24 : 12, K, fat(p.gside),
+                                                dat(p.cls_part), g_head ? g_head + 2 * o.m : nullptr, dm, s)) return e;
+          g.g_level = nullptr;
+          g.g_side = fat(p.gside);
+          hd.side_out = nullptr;
+          g_head = nullptr;          // (written above; the finalize kernel must not overwrite it)
+        }
         mark("epi_bwd:" + n);   // pass A: f64 sums + parameter-gradient records
         if (int e = launch_sse_bwd(p.d.dtype, at(r.raw), fat(r.mean), fat(r.rstd), r.cout, sse_params(o), g, hd, nullptr, nullptr,
                                    nullptr, dat(p.stats), fat(p.pgrad), dm, s)) return e;
         mark("stats");
-        float* g_head = grads[find_param(reg, o.head == 0 ? "dc0_0.weight" : "dc0_1.weight")];
         const int i_se2 = o.gates == 2 ? find_param(reg, n + ".conv_se2.weight") : -1;
         if (int e = launch_gate_bwd_finalize(dat(p.stats), P_slots, r.cout, dm.N, dm.vox(), fat(p.m1), fat(p.m2), fat(p.pgrad),
                                              dm.N * P_slots, grads[find_param(reg, n + ".conv_se.weight")],

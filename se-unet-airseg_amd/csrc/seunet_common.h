@@ -378,6 +378,15 @@ int launch_upsample2_fwd(int dtype, const void* in, int C, void* out, Dims din, 
 int launch_upsample2_bwd(int dtype, const void* g_out, int C, void* g_in, int accumulate,
                          Dims din, hipStream_t s);
 int launch_multi_zero(float* const* ptrs, const int* counts, int n, hipStream_t s);
+// n_classes > 1: the general head path (classes.hip)
+int class_max();
+int class_grad_records(Dims d);
+int launch_side_to_level(const float* side, const float* head_w, int wstride, const float* drop, int drop_stride, int K, float* level,
+                         int accumulate, Dims d, hipStream_t s);
+int launch_level_to_side_grad(const float* glev, long long cstride, long long nstride, const float* side, const float* head_w, int wstride,
+                              const float* drop, int drop_stride, int K, float* g_side, double* partial, float* dhead, Dims d,
+                              hipStream_t s);
+int launch_class_bias_grad(const float* per_sample, int N, int K, float* out, hipStream_t s);
 // connected components / metrics (components.hip)
 size_t cc_workspace_bytes(int H, int W, int Z);
 int launch_largest_component(const unsigned char* vol, int H, int W, int Z, int rule, unsigned char* out, int* status_dev,

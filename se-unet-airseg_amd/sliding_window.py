@@ -48,6 +48,9 @@ def _assemble(model, x: torch.Tensor, pos, cube: int, step: int, batch: int, n_d
         raise RuntimeError("HIP path needs a GPU tensor (no CPU fallback)")
     if x.dim() != 5 or x.shape[0] != 1:
         raise ValueError(f"expected one case (1, C, X, Y, Z), got {tuple(x.shape)}")
+    if getattr(model, "n_classes", 1) != 1:
+        raise NotImplementedError("the window loops of the reference accumulate ONE probability volume (prediction.py:104-107): "
+                                  "n_classes must be 1")
     lib = _lib.load()
     x = x.contiguous().float()
     _, C_, X, Y, Z = x.shape

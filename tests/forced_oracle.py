@@ -63,11 +63,11 @@ def oracle_choices(orc, model, image):
     return signs, pools
 
 
-def forced_step(orc, batch, stage, signs, pools, slope=0.01, width_mult=1, drops=None):
+def forced_step(orc, batch, stage, signs, pools, slope=0.01, width_mult=1, drops=None, n_classes=1):
     """float64 oracle forward + stage loss + backward with the given choices imposed.  Returns (model with .grad, pred0,
     pred1, loss, number of sign choices that differ from float64's own, number of pool choices that differ).
     ``drops``: the two DropLayer scale tensors of a train-mode step (injected into the oracle like into the HIP path)."""
-    o = orc.build_oracle(batch["image"].shape[1], 1, width_mult, seed=0, train=drops is not None).double()
+    o = orc.build_oracle(batch["image"].shape[1], n_classes, width_mult, seed=0, train=drops is not None).double()
     calls = {"lrelu": 0, "pool": 0, "sign_flips": 0, "pool_flips": 0}
     real_lrelu, real_pool = F.leaky_relu, F.max_pool3d
 

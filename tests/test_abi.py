@@ -55,7 +55,11 @@ def test_pure_host_entry_points_without_gpu():
     bad = make_desc(1, 2, 1, 100, 128, 128, 1, _lib.BF16, 0, 0.01)      # not a multiple of 8
     assert lib.seunet_net_workspace_bytes(C.byref(bad)) == 0
     assert "multiples of 8" in _lib.last_error()
-    bad = make_desc(1, 2, 3, 64, 64, 64, 1, _lib.BF16, 0, 0.01)
+    three = make_desc(1, 2, 3, 64, 64, 64, 1, _lib.BF16, 0, 0.01)       # n_classes = 3: the general head path (side maps kept)
+    one = make_desc(1, 2, 1, 64, 64, 64, 1, _lib.BF16, 0, 0.01)
+    assert lib.seunet_net_workspace_bytes(C.byref(three)) > lib.seunet_net_workspace_bytes(C.byref(one)) > 0
+    assert registry(three) == orc.parameter_registry(2, 3, 1)
+    bad = make_desc(1, 2, 9, 64, 64, 64, 1, _lib.BF16, 0, 0.01)
     assert lib.seunet_net_workspace_bytes(C.byref(bad)) == 0 and "n_classes" in _lib.last_error()
     assert lib.seunet_conv_wpack_bytes(_lib.BF16, 27, 64, 32) == 27 * 4 * 32 * 32
     assert lib.seunet_conv3d_wgrad_workspace_bytes(27, 64, 32) > 0
@@ -77,7 +81,7 @@ def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
         "int main(void) {\n"
         "  seunet_net_desc d = {1, 2, 1, 64, 64, 64, 1, SEUNET_BF16, SEUNET_CONV_MFMA, 0.01f, 1e-5f};\n"
         '  printf("%d %d %d\\n", seunet_version(), seunet_net_param_count(&d), seunet_net_workspace_bytes(&d) > 0);\n'
-        "  d.n_classes = 3;\n"
+        "  d.n_classes = 9;\n"
         '  if (seunet_net_workspace_bytes(&d) != 0) return 2;\n'
         '  printf("%s\\n", seunet_last_error());\n'
         "  return 0;\n}\n")

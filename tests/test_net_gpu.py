@@ -593,6 +593,49 @@ def test_results_do_not_depend_on_the_prior_contents_of_the_workspace(A, orc, dt
     assert not bad, bad
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_three_classes_forward_backward_fp32(A, orc, train):
+    """SE_UNet(in_channel, n_classes) with n_classes = 3 (SE_UNet.py:100,150-151: the two 1x1x1 heads map 24 / 12 side channels to
+    n_classes logits).  No reference caller uses it; the HIP path runs the heads on its general form (csrc/classes.hip).  Logits
+    (B, 3, D, H, W) against the oracle, loss (Dice over all classes, the reference's flattening ratio) and every gradient against
+    float64 with the same discrete choices -- eval mode and train mode (DropLayer scales injected)."""
+    import forced_oracle as FO
+    K = 3
+    m = A.SE_UNet(in_channel=2, n_classes=K, act_dtype="fp32")
+    m.load_state_dict(orc.deterministic_state_dict(2, K, 1, seed=0))
+    m = m.cuda().train(train)
+    b = orc.synthetic_batch(2, (32, 32, 32), 2, seed=31)
+    g = torch.Generator().manual_seed(7)
+    label = (torch.rand(2, K, 32, 32, 32, generator=g) < 0.05).float()
+    drops = None
+    if train:
+        drops = (orc.drop_scale_from_uniform(torch.rand(2, 24, 1, 1, 1, generator=g), 24),
+                 orc.drop_scale_from_uniform(torch.rand(2, 12, 1, 1, 1, generator=g), 12))
+    o = orc.build_oracle(2, K, 1, seed=0, train=train)
+    with torch.no_grad():
+        pe, pd = o(b["image"], *drops) if train else o(b["image"])
+    ge, gd = m(b["image"].cuda(), drop_scales=drops) if train else m(b["image"].cuda())
+    assert tuple(ge.shape) == (2, K, 32, 32, 32) == tuple(gd.shape)
+    assert float((ge.detach().cpu() - pe).abs().max()) < 1e-4 and float((gd.detach().cpu() - pd).abs().max()) < 1e-4
+    loss = A.fused_stage_loss(1, ge, gd, label.cuda())
+    loss.backward()
+    m.eval()
+    _, _, inter = m.forward_with_intermediates(b["image"].cuda(), FO.LRELU_ORDER)
+    m.train(train)
+    signs, pools = FO.path_choices(inter)
+    bb = dict(b, label=label, weight=torch.ones_like(label), skel=torch.zeros_like(label))
+    of, fe, fd, lf, nsf, npf = FO.forced_step(orc, bb, 1, signs, pools, drops=drops, n_classes=K)
+    assert abs(float(loss.detach()) - lf) < 1e-5
+    err = _rel_errors(m, of)
+    v = np.array(list(err.values()))
+    print(f"n_classes=3 train={train}: gradient rel-L2 vs same-choice float64 ({nsf} / {npf} choices differ): median {np.median(v):.2e} max {v.max():.2e}")
+    bad = {k: e for k, e in err.items() if e > 3e-5}
+    assert not bad, bad
+    assert tuple(m.dc0_0.weight.grad.shape) == (K, 24, 1, 1, 1) and tuple(m.dc0_1.bias.grad.shape) == (K,)
+    with pytest.raises(NotImplementedError):
+        A.sliding_window_predict(m.eval(), torch.zeros(1, 2, 32, 32, 32, device="cuda"), cube=32, step=16)
+
+
 @pytest.mark.parametrize("dtype,reps", [("fp32", 300), ("bf16", 400)])
 def test_step_is_bitwise_stable_while_another_process_shares_the_gpu(dtype, reps):
     """tests/stress_shared_gpu.py: one process repeats a 1 x 2 x 32^3 step while a second one runs steps of another shape on the same
