@@ -171,6 +171,17 @@ conv_march_kernel(MarchArgs a) {
     const uint4* wp = reinterpret_cast<const uint4*>(a.wpack) + (size_t)g16 * (NTAP * KS * 64) + lane;
 #pragma unroll
     for (int k = 0; k < NTAP * KS; ++k) wreg[k] = __builtin_bit_cast(mbf16x8, wp[k * 64]);
+    // 64-channel inputs: 216 weight registers + fragments + addresses do not fit the 256 architectural VGPRs, and left alone the
+    // allocator parks weights in the accumulator half and copies them back before every use (170 v_accvgpr_read per step of the
+    // dc5 forward: the forward's 2.68 of 4 busy SIMDs against the data gradient's 2.98).  The matrix instruction takes its A
+    // operand from either half, so the fragments of K-step 1 are PINNED to the accumulator half here (an empty asm with an "a"
+    // constraint; the MFMAs stay builtins, so the scheduler still interleaves the epilogue): 511 -> 140 copies per three steps,
+    // the rest being the epilogue's reads of finished accumulators (round 4; counted on the ISA of every KS = 2 configuration)
+    if constexpr (KS == 2) {
+#pragma unroll
+      for (int k = 0; k < NTAP * KS; ++k)
+        if ((k % KS) == 1) asm volatile("" : "+a"(wreg[k]));
+    }
   }
 
   // ---- DMA plan: item it of this wave = instruction number wave + 4 * it of the plane image ----
