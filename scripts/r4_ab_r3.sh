@@ -1,4 +1,6 @@
-# same-box A/B: round-3 tree (_r3/, its own library and bench.py) vs this tree
+# same-box A/B: round-3 tree (_r3/, its own library and bench.py) vs this tree.  _r3/ is not tracked: create it with
+#   git worktree add -f _r3 e7350ee && make -C _r3/se-unet-airseg_amd/csrc -j8
+# (and remove it again with `git worktree remove --force _r3`)
 set -e
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r04
