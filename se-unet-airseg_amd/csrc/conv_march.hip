@@ -83,6 +83,7 @@ struct MarchArgs {
   double* stats; const void* zero;
   int N, D, H, W;
   int nyb, nxb, nseg, zsteps, nblk;      // patches, z segments (per parity class), output planes per segment, N blocks
+  int buf;                               // the source(s) of a sample fit one 32-bit buffer descriptor (see march_dma16_buf)
 };
 
 static constexpr int MA_TX = 32, MA_NW = 4, MA_HXP = 36, MA_PF = 2, MA_RING = 3;
@@ -117,6 +118,16 @@ __device__ __forceinline__ void march_dma16(const void* gsrc, unsigned lds_dst) 
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// The same through a buffer descriptor (round 4, single-source launches): base + scalar offset + per-lane offset, and a lane whose
+// offset lies beyond num_records writes ZEROS into the LDS (probed on gfx950: scripts/probes/blds_oob.hip) -- the padding of a
+// plane image needs no zero page, no per-lane pointer select, no validity mask and no 64-bit address.  In the main loop of the
+// dc5 data gradient that is 1.25 -> 1.06 other instructions per MFMA and 65 -> 12 scalar-register spill reads.
+typedef unsigned int mu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void march_dma16_buf(unsigned voff, mu32x4 rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
 template <int N> __device__ __forceinline__ void march_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int NP> __device__ __forceinline__ int march_swz(int hx) {
@@ -132,7 +143,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // MODE 0: forward (bias + InstanceNorm partial sums); 1: data gradient; 2: data gradient with accumulation (+=)
-template <typename T, int KS, int NGW, int RYW, int DIL, int MODE>
+// BUF: one source tensor whose sample is < 4 GB: the plane DMA goes through a buffer descriptor (march_dma16_buf)
+template <typename T, int KS, int NGW, int RYW, int DIL, int MODE, bool BUF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_march_kernel(MarchArgs a) {
   using Geo = MarchGeo<KS, NGW, RYW, DIL, MODE>;
@@ -184,9 +196,29 @@ conv_march_kernel(MarchArgs a) {
     }
   }
 
-  // ---- DMA plan: item it of this wave = instruction number wave + 4 * it of the plane image ----
-  unsigned doff[ITEMS];            // byte offset inside a z-plane of the source; bit 31 = second source; ~0 = padding
   const long long plane_bytes = (long long)a.H * a.W * a.srcC * (long long)sizeof(T);
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
+  const unsigned char* src0_n = reinterpret_cast<const unsigned char*>(a.src0) + (long long)n * a.D * plane_bytes;
+  const unsigned char* src1_n = reinterpret_cast<const unsigned char*>(a.nsrc > 1 ? a.src1 : a.src0) + (long long)n * a.D * plane_bytes;
+  // plane of step s -> ring slot; every wave issues exactly ITEMS instructions (the vmcnt arithmetic counts on it).  The
+  // plane-level part (validity, 64-bit plane bases, LDS slot base) is computed once per step (`plane_of`) and handed to the
+  // items: they sit in different scheduling regions, so the compiler recomputed it for each of them, and with one wave per
+  // SIMD every scalar instruction takes an issue slot from the MFMA stream
+  // BUF: ONE descriptor for the sample -- base = the lower of the (one or two) source pointers, a lane of the other source adds the
+  // distance between the two tensors (the launcher checked that distance + sample fit 32 bits; net.cpp keeps dc5's two sources
+  // next to each other in the arena), num_records = everything up to the end of the upper tensor's sample
+  unsigned s_lo = 0, s_hi = 0, sample_bytes = 0, off_s0 = 0, off_s1 = 0;
+  if constexpr (BUF) {
+    const unsigned char* base = src1_n < src0_n ? src1_n : src0_n;
+    off_s0 = (unsigned)(src0_n - base);
+    off_s1 = (unsigned)(src1_n - base);
+    const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+    s_lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    s_hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xFFFFu;
+    sample_bytes = (off_s0 > off_s1 ? off_s0 : off_s1) + (unsigned)((long long)a.D * plane_bytes);
+  }
+  // ---- DMA plan: item it of this wave = instruction number wave + 4 * it of the plane image ----
+  unsigned doff[ITEMS];            // byte offset inside a z-plane of the source; bit 31 = second source (BUF: + that source's distance from the base); ~0 = padding
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
     const int id = wave + MA_NW * it;
@@ -199,16 +231,11 @@ conv_march_kernel(MarchArgs a) {
     const bool s1 = ch >= a.srcC;
     const int cl = s1 ? ch - a.srcC : ch;
     const bool ok = id < NI && hx < HX && hy < HY && y >= 0 && y < a.H && x >= 0 && x < a.W && (!s1 || a.nsrc > 1);
-    doff[it] = ok ? ((unsigned)(((y * a.W + x) * a.srcC + cl) * (int)sizeof(T)) | (s1 ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
+    if constexpr (BUF) doff[it] = ok ? (unsigned)(((y * a.W + x) * a.srcC + cl) * (int)sizeof(T)) + (s1 ? off_s1 : off_s0) : 0xFFFFFFFFu;
+    else doff[it] = ok ? ((unsigned)(((y * a.W + x) * a.srcC + cl) * (int)sizeof(T)) | (s1 ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
   }
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
-  const unsigned char* src0_n = reinterpret_cast<const unsigned char*>(a.src0) + (long long)n * a.D * plane_bytes;
-  const unsigned char* src1_n = reinterpret_cast<const unsigned char*>(a.nsrc > 1 ? a.src1 : a.src0) + (long long)n * a.D * plane_bytes;
-  // plane of step s -> ring slot; every wave issues exactly ITEMS instructions (the vmcnt arithmetic counts on it).  The
-  // plane-level part (validity, 64-bit plane bases, LDS slot base) is computed once per step (`plane_of`) and handed to the
-  // items: they sit in different scheduling regions, so the compiler recomputed it for each of them, and with one wave per
-  // SIMD every scalar instruction takes an issue slot from the MFMA stream
-  struct PlaneRef { const unsigned char* b0; const unsigned char* b1; unsigned lds; bool ok; };
+
+  struct PlaneRef { const unsigned char* b0; const unsigned char* b1; unsigned lds; bool ok; unsigned soff; unsigned nrec; };
   auto plane_of = [&](int s, int slot) __attribute__((always_inline)) -> PlaneRef {
     PlaneRef r;
     const int pl = q0 - 1 + s;
@@ -217,12 +244,20 @@ conv_march_kernel(MarchArgs a) {
     const long long zb = (long long)(r.ok ? z : 0) * plane_bytes;  // (scalar)
     r.b0 = src0_n + zb; r.b1 = src1_n + zb;
     r.lds = lds_base + (unsigned)(slot * PLB);
+    r.soff = (unsigned)zb;                                          // (BUF: < 2^32, checked by the launcher)
+    r.nrec = r.ok ? sample_bytes : 0u;
     return r;
   };
   auto dma_item = [&](const PlaneRef& r, auto it_c) __attribute__((always_inline)) {
     constexpr int it = decltype(it_c)::value;
     if constexpr (it < ITEMS) {
       const bool real = wave + MA_NW * it < NI;                     // wave-uniform
+      if constexpr (BUF) {      // (doff: the lane's offset inside a plane, 0xFFFFFFFF for padding; a padding item reads zero records)
+        mu32x4 rs;
+        rs.x = s_lo; rs.y = s_hi; rs.z = real ? r.nrec : 0u; rs.w = 0x00020000u;
+        march_dma16_buf(doff[it], rs, r.soff, real ? r.lds + (unsigned)((wave + MA_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
+        return;
+      }
       const unsigned d = doff[it];
       const unsigned char* gp = ((d & 0x80000000u) ? r.b1 : r.b0) + (d & 0x7FFFFFFFu);
       gp = (r.ok && real && d != 0xFFFFFFFFu) ? gp : zero_page;
@@ -634,14 +669,22 @@ int launch_conv_march_pack_multi(int dtype, const MarchPackJob* jobs, int n, hip
   return 0;
 }
 
-template <typename T, int KS, int NGW, int RYW, int DIL, int MODE>
-static int march_launch(const MarchArgs& a, dim3 grid, hipStream_t s) {
+template <typename T, int KS, int NGW, int RYW, int DIL, int MODE, bool BUF>
+static int march_launch_buf(const MarchArgs& a, dim3 grid, hipStream_t s) {
   using Geo = MarchGeo<KS, NGW, RYW, DIL, MODE>;
   static unsigned long long configured = 0;
-  if (int e = configure_kernel_lds(configured, reinterpret_cast<const void*>(&conv_march_kernel<T, KS, NGW, RYW, DIL, MODE>), Geo::LDS)) return e;
-  conv_march_kernel<T, KS, NGW, RYW, DIL, MODE><<<grid, MA_NW * 64, Geo::LDS, s>>>(a);
+  if (int e = configure_kernel_lds(configured, reinterpret_cast<const void*>(&conv_march_kernel<T, KS, NGW, RYW, DIL, MODE, BUF>), Geo::LDS)) return e;
+  conv_march_kernel<T, KS, NGW, RYW, DIL, MODE, BUF><<<grid, MA_NW * 64, Geo::LDS, s>>>(a);
   SEUNET_LAUNCH_CHECK();
   return 0;
+}
+// the data gradients always have one source (the gradient of the raw conv output); the forward has one or two
+template <typename T, int KS, int NGW, int RYW, int DIL, int MODE>
+static int march_launch(const MarchArgs& a, dim3 grid, hipStream_t s) {
+  if constexpr (MODE == 0) {
+    if (!a.buf) return march_launch_buf<T, KS, NGW, RYW, DIL, MODE, false>(a, grid, s);   // two sources too far apart for one descriptor
+  }
+  return march_launch_buf<T, KS, NGW, RYW, DIL, MODE, true>(a, grid, s);
 }
 template <typename T, int KS, int NGW, int RYW, int DIL>
 static int march_launch_mode(int mode, const MarchArgs& a, dim3 grid, hipStream_t s) {
@@ -675,6 +718,15 @@ int launch_conv_march(int dtype, int dil, const SrcList& src, const void* wpack,
     SEUNET_CHECK((long long)d.vox() * dst.C[i] * 2 < (1LL << 31), "conv_march: one sample of destination %d exceeds the 32-bit offsets of this kernel", i);
   }
   SEUNET_CHECK((long long)d.H * d.W * src.C[0] * 2 < (1LL << 31), "conv_march: one plane of the source exceeds the 31-bit offsets of this kernel");
+  const bool fwd_probe = bias != nullptr || stats != nullptr;
+  const long long sample_src = (long long)d.vox() * src.C[0] * 2;
+  long long span = sample_src;           // bytes from the lower source's sample to the end of the upper source's sample
+  if (src.n > 1) {
+    const long long dist = reinterpret_cast<const char*>(src.ptr[1]) - reinterpret_cast<const char*>(src.ptr[0]);
+    span += dist < 0 ? -dist : dist;
+  }
+  const bool buf_ok = span < (1LL << 32);
+  SEUNET_CHECK(buf_ok || (fwd_probe && src.n > 1), "conv_march: the source of one sample exceeds the 32-bit offsets of this kernel");
   const bool fwd = bias != nullptr || stats != nullptr;
   SEUNET_CHECK(!(fwd && any_acc), "conv_march: accumulation into the destination is a data-gradient feature (no bias, no statistics)");
   SEUNET_CHECK(!stats || dst.n == 1, "conv_march: statistics need a single destination");
@@ -688,6 +740,7 @@ int launch_conv_march(int dtype, int dil, const SrcList& src, const void* wpack,
   a.dcum1 = dst.n > 1 ? dst.C[0] : a.cout;
   a.dcum2 = dst.n > 2 ? dst.C[0] + dst.C[1] : a.cout;
   a.stats = stats; a.zero = device_zero_page();
+  a.buf = buf_ok ? 1 : 0;
   SEUNET_CHECK(a.zero != nullptr, "conv_march: no zero page on this device");
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const int mode = fwd ? 0 : (any_acc ? 2 : 1);

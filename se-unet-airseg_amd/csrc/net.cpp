@@ -177,9 +177,16 @@ struct Plan {
     esz = dtype_size(d.dtype);
     for (int l = 0; l < 4; ++l) dims[l] = Dims{d.batch, d.d >> l, d.h >> l, d.w >> l};
     for (int t = 0; t < T_COUNT; ++t) C[t] = kT[t].cbase == 0 ? 8 : kT[t].cbase * d.width_mult;
+    // (the two sources of a two-source marching layer are allocated next to each other: the kernel then reaches both through one
+    // 32-bit buffer descriptor, conv_march.hip `BUF`; dc5 = conv(cat(up2(d1), e1)) is that layer at width 1)
+    bool placed[T_COUNT] = {};
     for (int t = 0; t < T_COUNT; ++t) {
       const size_t bytes = (size_t)d.batch * dims[kT[t].level].vox() * C[t] * esz;
-      feat[t] = take(bytes);
+      if (!placed[t]) { feat[t] = take(bytes); placed[t] = true; }
+      if (t == T_E1 && !placed[T_D2U]) {
+        feat[T_D2U] = take((size_t)d.batch * dims[kT[T_D2U].level].vox() * C[T_D2U] * esz);
+        placed[T_D2U] = true;
+      }
       grad[t] = is_input(t) ? 0 : take(bytes);
     }
     size_t gx_max = 0, wg_max = 0, xw_max = 0, xmom_max = 0;
