@@ -178,14 +178,15 @@ struct Plan {
     for (int l = 0; l < 4; ++l) dims[l] = Dims{d.batch, d.d >> l, d.h >> l, d.w >> l};
     for (int t = 0; t < T_COUNT; ++t) C[t] = kT[t].cbase == 0 ? 8 : kT[t].cbase * d.width_mult;
     // (the two sources of a two-source marching layer are allocated next to each other: the kernel then reaches both through one
-    // 32-bit buffer descriptor, conv_march.hip `BUF`; dc5 = conv(cat(up2(d1), e1)) is that layer at width 1)
+    // 32-bit buffer descriptor, conv_march.hip `BUF` and wgrad_march.hip)
     bool placed[T_COUNT] = {};
     for (int t = 0; t < T_COUNT; ++t) {
       const size_t bytes = (size_t)d.batch * dims[kT[t].level].vox() * C[t] * esz;
       if (!placed[t]) { feat[t] = take(bytes); placed[t] = true; }
-      if (t == T_E1 && !placed[T_D2U]) {
-        feat[T_D2U] = take((size_t)d.batch * dims[kT[T_D2U].level].vox() * C[T_D2U] * esz);
-        placed[T_D2U] = true;
+      const int mate = t == T_E1 ? T_D2U : t == T_E3 ? T_D1U : t == T_E5 ? T_E8 : -1;   // (dc5, dc3, dc1: skip next to up-sampled)
+      if (mate >= 0 && !placed[mate]) {
+        feat[mate] = take((size_t)d.batch * dims[kT[mate].level].vox() * C[mate] * esz);
+        placed[mate] = true;
       }
       grad[t] = is_input(t) ? 0 : take(bytes);
     }
@@ -220,7 +221,9 @@ struct Plan {
       r.mean = take((size_t)d.batch * r.cout * 4);
       r.rstd = take((size_t)d.batch * r.cout * 4);
       // small-channel 3x3x3 layers with one source tensor (ec1 / ec2 / ec3 / dc6 at width 1) run on the streaming kernel
-      const bool stream_ok = use_stream && o.kind == OP_GATED && o.nsrc == 1 && d.conv_impl != SEUNET_CONV_NAIVE;
+      // (the streaming kernels address one sample through 32-bit buffer offsets; a sample of 4 GB or more takes the general kernels)
+      const bool stream_ok = use_stream && o.kind == OP_GATED && o.nsrc == 1 && d.conv_impl != SEUNET_CONV_NAIVE &&
+                             (long long)dims[kT[o.dst].level].D * dims[kT[o.dst].level].H * dims[kT[o.dst].level].W * 32 * (long long)esz < 0xFFFFFFFFll;
       r.stream_f = stream_ok && conv_stream_supported(d.dtype, 27, o.dil, C[o.src[0]], r.cout);
       r.stream_d = stream_ok && r.need_dgrad && conv_stream_supported(d.dtype, 27, o.dil, r.cout, C[o.src[0]]);
       // 32 / 64-input-channel 3x3x3 layers of the levels that fill the chip with 32-voxel rows run on the marching kernel

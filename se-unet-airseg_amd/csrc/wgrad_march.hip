@@ -34,7 +34,7 @@ struct WmArgs {
   const void* src0; const void* src1;   // X: one or two tensors of srcC channels each (virtual concatenation)
   int srcC, nsrc;
   const void* dy; int cout;
-  float* slab; const void* zero;
+  float* slab;
   int N, D, H, W;
   int nyb, nxb, nseg, zsteps;           // patches, z segments per parity class, dY planes per segment
   int nco;                              // output-channel combos (blockIdx.y = ci combo * nco + co combo)
@@ -64,6 +64,14 @@ __device__ __forceinline__ void wm_dma16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// through a buffer descriptor (round 4; see conv_march.hip march_dma16_buf): base + scalar plane offset + the lane's constant offset;
+// a lane beyond num_records -- a padding voxel, or any lane of a plane outside the march (zero records) -- writes ZEROS into the LDS
+typedef unsigned int wmu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wm_dma16_buf(unsigned voff, wmu32x4 rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void wm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -166,7 +174,6 @@ wgrad_march_kernel(WmArgs a) {
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[k][t] = wmf32x4{0.f, 0.f, 0.f, 0.f};
 
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
   const long long xplane = (long long)a.H * a.W * a.srcC * (long long)sizeof(T);
   const long long yplane = (long long)a.H * a.W * a.cout * (long long)sizeof(T);
 
@@ -183,7 +190,22 @@ wgrad_march_kernel(WmArgs a) {
     const int Z = min(a.zsteps, nplanes - q0);            // dY planes of this march (may be <= 0 for a ragged last segment)
     const int nsteps = Z > 0 ? Z + 2 : 0;                 // X planes q0-1 .. q0+Z
 
-    // ---- DMA plan of this item: byte offset inside a z-plane; bit 31 = second source; ~0 = padding ----
+    const unsigned char* x0_n = reinterpret_cast<const unsigned char*>(a.src0) + (long long)n * a.D * xplane;
+    const unsigned char* x1_n = reinterpret_cast<const unsigned char*>(a.nsrc > 1 ? a.src1 : a.src0) + (long long)n * a.D * xplane;
+    const unsigned char* dy_n = reinterpret_cast<const unsigned char*>(a.dy) + (long long)n * a.D * yplane;
+    // ONE descriptor for the X operand of this sample (base = the lower of the one or two source pointers, a lane of the other source
+    // adds the distance between the tensors; the launcher checked that it all fits 32 bits), one for dY
+    const unsigned char* xbase = x1_n < x0_n ? x1_n : x0_n;
+    const unsigned off_x0 = (unsigned)(x0_n - xbase), off_x1 = (unsigned)(x1_n - xbase);
+    const unsigned xspan = (off_x0 > off_x1 ? off_x0 : off_x1) + (unsigned)((long long)a.D * xplane);
+    const unsigned yspan = (unsigned)((long long)a.D * yplane);
+    unsigned xlo, xhi, ylo, yhi;
+    {
+      const unsigned long long u = reinterpret_cast<unsigned long long>(xbase), w = reinterpret_cast<unsigned long long>(dy_n);
+      xlo = __builtin_amdgcn_readfirstlane((unsigned)u); xhi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xFFFFu;
+      ylo = __builtin_amdgcn_readfirstlane((unsigned)w); yhi = __builtin_amdgcn_readfirstlane((unsigned)(w >> 32)) & 0xFFFFu;
+    }
+    // ---- DMA plan of this item: the lane's byte offset from the descriptor base inside a z-plane; ~0 = padding ----
     unsigned dox[ITEMSX], doy[ITEMSY];
 #pragma unroll
     for (int it = 0; it < ITEMSX; ++it) {
@@ -196,7 +218,7 @@ wgrad_march_kernel(WmArgs a) {
       const bool s1 = ch >= a.srcC;
       const int cl = s1 ? ch - a.srcC : ch;
       const bool ok = id < NIX && hx < HX && hy < HY && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      dox[it] = ok ? ((unsigned)(((y * a.W + x) * a.srcC + cl) * (int)sizeof(T)) | (s1 ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
+      dox[it] = ok ? (unsigned)(((y * a.W + x) * a.srcC + cl) * (int)sizeof(T)) + (s1 ? off_x1 : off_x0) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int it = 0; it < ITEMSY; ++it) {
@@ -207,25 +229,23 @@ wgrad_march_kernel(WmArgs a) {
       const int y = y0 + r, x = x0 + xx;
       doy[it] = (y < a.H && x < a.W) ? (unsigned)(((y * a.W + x) * a.cout + ch) * (int)sizeof(T)) : 0xFFFFFFFFu;
     }
-    const unsigned char* x0_n = reinterpret_cast<const unsigned char*>(a.src0) + (long long)n * a.D * xplane;
-    const unsigned char* x1_n = reinterpret_cast<const unsigned char*>(a.nsrc > 1 ? a.src1 : a.src0) + (long long)n * a.D * xplane;
-    const unsigned char* dy_n = reinterpret_cast<const unsigned char*>(a.dy) + (long long)n * a.D * yplane;
 
     // DMA instruction `it` of the planes of step s (X plane -> slot xs, dY plane s -> slot ys); every wave issues exactly TOT
     // instructions per step (padding instructions land in the dump area)
     // (the plane-level part -- validity, 64-bit plane base, LDS slot base -- is computed ONCE per step by `plane_of` and handed
     // to the items: with one wave per SIMD every scalar instruction takes an issue slot from the MFMA stream, and the items
     // sit in different scheduling regions, so the compiler recomputed it for each of them)
-    struct PlaneRef { const unsigned char* x0; const unsigned char* x1; const unsigned char* y; unsigned xlds, ylds; bool xok, yok; };
+    struct PlaneRef { unsigned xsoff, ysoff, xrec, yrec; unsigned xlds, ylds; bool yok; };
     auto plane_of = [&](int s, int xs, int ys) __attribute__((always_inline)) -> PlaneRef {
       PlaneRef r;
       const int pl = q0 - 1 + s;
       const int z = pz + DIL * pl;
-      r.xok = pl >= 0 && z < a.D && s < nsteps;                       // wave-uniform
-      const long long zb = (long long)(r.xok ? z : 0) * xplane;
-      r.x0 = x0_n + zb; r.x1 = x1_n + zb;
+      const bool xok = pl >= 0 && z < a.D && s < nsteps;              // wave-uniform
+      r.xsoff = (unsigned)((long long)(xok ? z : 0) * xplane);
+      r.xrec = xok ? xspan : 0u;
       r.yok = s < Z;                                                  // wave-uniform
-      r.y = dy_n + (long long)(r.yok ? pz + DIL * (q0 + s) : 0) * yplane;
+      r.ysoff = (unsigned)((long long)(r.yok ? pz + DIL * (q0 + s) : 0) * yplane);
+      r.yrec = r.yok ? yspan : 0u;
       r.xlds = lds_base + (unsigned)(xs * PLBX);
       r.ylds = lds_base + (unsigned)(Geo::YOFF + ys * PLBY);
       return r;
@@ -234,15 +254,14 @@ wgrad_march_kernel(WmArgs a) {
       constexpr int it = decltype(it_c)::value;
       if constexpr (it < ITEMSX) {
         const bool real = wave + WM_NW * it < NIX;                    // wave-uniform
-        const unsigned d = dox[it];
-        const unsigned char* gp = ((d & 0x80000000u) ? r.x1 : r.x0) + (d & 0x7FFFFFFFu);
-        gp = (r.xok && d != 0xFFFFFFFFu) ? gp : zero_page;
-        wm_dma16(gp, real ? r.xlds + (unsigned)((wave + WM_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
+        wmu32x4 rs;
+        rs.x = xlo; rs.y = xhi; rs.z = real ? r.xrec : 0u; rs.w = 0x00020000u;
+        wm_dma16_buf(dox[it], rs, r.xsoff, real ? r.xlds + (unsigned)((wave + WM_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
       } else {
         constexpr int iy = it - ITEMSX;
-        const unsigned d = doy[iy];
-        const unsigned char* gp = (r.yok && d != 0xFFFFFFFFu) ? r.y + d : zero_page;
-        wm_dma16(gp, r.yok ? r.ylds + (unsigned)((wave + WM_NW * iy) * 1024) : lds_base + (unsigned)Geo::DUMP);
+        wmu32x4 rs;
+        rs.x = ylo; rs.y = yhi; rs.z = r.yrec; rs.w = 0x00020000u;
+        wm_dma16_buf(doy[iy], rs, r.ysoff, r.yok ? r.ylds + (unsigned)((wave + WM_NW * iy) * 1024) : lds_base + (unsigned)Geo::DUMP);
       }
     };
 
@@ -393,6 +412,18 @@ static bool wgrad_march_cfg(int dtype, int taps, int dil, const SrcList& x, int 
   if (dtype_size(dtype) != 2 || taps != 27 || (dil != 1 && dil != 2)) return false;
   if (x.n < 1 || x.n > 2 || (x.n == 2 && x.C[0] != x.C[1])) return false;
   if (cin_logical != x.total() || cin_logical % 32 || cout % 32 || x.C[0] % 8) return false;
+  {
+    // the plane DMA addresses a sample through 32-bit buffer offsets: one sample of dY, and the one or two X tensors of a sample
+    // INCLUDING the distance between them, must fit (the network's plan places the halves of a concatenation next to each other;
+    // anything larger goes to the tiled kernel)
+    const long long esz = 2, xs = (long long)d.D * d.H * d.W * x.C[0] * esz, ys = (long long)d.D * d.H * d.W * cout * esz;
+    long long dist = 0;
+    if (x.n == 2) {
+      dist = reinterpret_cast<const unsigned char*>(x.ptr[1]) - reinterpret_cast<const unsigned char*>(x.ptr[0]);
+      if (dist < 0) dist = -dist;
+    }
+    if (dist + xs >= 0xFFFFFFFFll || ys >= 0xFFFFFFFFll) return false;
+  }
   if (size_gate) {
     // where it beats the tiled kernel (isolated launches, 4 samples): the fine levels (rows of >= 32 voxels, >= 48^3); every
     // dilation-2 layer down to 16^3 (the tiled kernel works on parity sub-lattices there: 32^3 64 -> 64 0.057 vs 0.080 ms, 16^3
@@ -434,8 +465,6 @@ int launch_wgrad_march(int dtype, int taps, int dil, const SrcList& x, int cin_l
   WmArgs a{};
   a.src0 = x.ptr[0]; a.src1 = x.n > 1 ? x.ptr[1] : nullptr; a.srcC = x.C[0]; a.nsrc = x.n;
   a.dy = dy; a.cout = cout;
-  a.zero = device_zero_page();
-  SEUNET_CHECK(a.zero != nullptr, "wgrad_march: cannot allocate the device zero page");
   a.slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + 256);
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   a.nyb = cdiv(d.H, WM_RY); a.nxb = cdiv(d.W, WM_TX);

@@ -24,7 +24,7 @@ typedef bf16_t bf16x8w __attribute__((ext_vector_type(8)));
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
 struct WsArgs {
-  const void* x; const void* dy; float* slab; const void* zero;
+  const void* x; const void* dy; float* slab;
   int N, D, H, W;
   int nyb, nxb, nzseg, zsteps;
 };
@@ -54,6 +54,14 @@ __device__ __forceinline__ void ws_dma16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// through a buffer descriptor (round 4; see conv_stream.hip stream_dma16_buf): base + scalar plane offset + the lane's constant
+// offset; a lane beyond num_records -- a padding voxel, or any lane of a plane outside the march (zero records) -- writes ZEROS
+typedef unsigned int wsu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ws_dma16_buf(unsigned voff, wsu32x4 rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -88,7 +96,13 @@ wgrad_stream_kernel(WsArgs a) {
   const long long xplane_bytes = (long long)a.H * a.W * CIN * 2, yplane_bytes = (long long)a.H * a.W * COUT * 2;
   const unsigned char* x_n = reinterpret_cast<const unsigned char*>(a.x) + (long long)n * a.D * xplane_bytes;
   const unsigned char* y_n = reinterpret_cast<const unsigned char*>(a.dy) + (long long)n * a.D * yplane_bytes;
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;
+  const unsigned xspan = (unsigned)((long long)a.D * xplane_bytes), yspan = (unsigned)((long long)a.D * yplane_bytes);   // (< 2^32: launcher)
+  unsigned xlo, xhi, ylo, yhi;
+  {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(x_n), w = reinterpret_cast<unsigned long long>(y_n);
+    xlo = __builtin_amdgcn_readfirstlane((unsigned)u); xhi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xFFFFu;
+    ylo = __builtin_amdgcn_readfirstlane((unsigned)w); yhi = __builtin_amdgcn_readfirstlane((unsigned)(w >> 32)) & 0xFFFFu;
+  }
 
   // ---- DMA plans (per lane, march-invariant) ----
   unsigned xoff[XITEMS], xlds[XITEMS];
@@ -118,16 +132,20 @@ wgrad_stream_kernel(WsArgs a) {
     const bool real = wave + WS_NW * it < NP * G;
     const int pl = q0 - 1 + s, z = pz + DIL * pl;
     const bool zok = real && pl >= 0 && z < a.D && s < nsteps;
-    const unsigned char* gp = (zok && xoff[it] != 0xFFFFFFFFu) ? x_n + (long long)(zok ? z : 0) * xplane_bytes + xoff[it] : zero_page;
-    ws_dma16(gp, real ? lds_base + (unsigned)(slot * XPLANE) + xlds[it] : lds_base + (unsigned)Geo::DUMP);
+    wsu32x4 rs;
+    rs.x = xlo; rs.y = xhi; rs.z = zok ? xspan : 0u; rs.w = 0x00020000u;
+    ws_dma16_buf(xoff[it], rs, (unsigned)((long long)(zok ? z : 0) * xplane_bytes),
+                 real ? lds_base + (unsigned)(slot * XPLANE) + xlds[it] : lds_base + (unsigned)Geo::DUMP);
   };
   auto dma_y = [&](int jd, int slot, auto it_c) __attribute__((always_inline)) {   // dY plane q0 - 2 + jd; zero outside [q0, q1)
     constexpr int it = decltype(it_c)::value;
     const bool real = wave + WS_NW * it < NDY;
     const int pl = q0 - 2 + jd, z = pz + DIL * pl;
     const bool zok = real && pl >= q0 && pl < q1;
-    const unsigned char* gp = (zok && yoff[it] != 0xFFFFFFFFu) ? y_n + (long long)(zok ? z : 0) * yplane_bytes + yoff[it] : zero_page;
-    ws_dma16(gp, real ? lds_base + (unsigned)(Geo::YOFF + slot * YPLANE + (wave + WS_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
+    wsu32x4 rs;
+    rs.x = ylo; rs.y = yhi; rs.z = zok ? yspan : 0u; rs.w = 0x00020000u;
+    ws_dma16_buf(yoff[it], rs, (unsigned)((long long)(zok ? z : 0) * yplane_bytes),
+                 real ? lds_base + (unsigned)(Geo::YOFF + slot * YPLANE + (wave + WS_NW * it) * 1024) : lds_base + (unsigned)Geo::DUMP);
   };
   auto dma_group = [&](int s, int xslot, int jd, int yslot, int part) __attribute__((always_inline)) {
     // part 0 / 1: first / second half of the instructions (spread over the two rows of a step); part 2: everything
@@ -342,10 +360,10 @@ int launch_wgrad_stream(int dtype, int dil, const void* x, int x_c, int cin_w, c
   SEUNET_CHECK(wgrad_stream_supported(dtype, 27, dil, x_c, dy_c), "wgrad_stream: unsupported shape (%d x %d channels, dilation %d)", x_c, dy_c, dil);
   SEUNET_CHECK(x && dy && dw && workspace && cin_w >= 1 && cin_w <= x_c && cout_w >= 1 && cout_w <= dy_c, "wgrad_stream: bad argument");
   SEUNET_CHECK(ws_bytes >= wgrad_stream_workspace_bytes(x_c, dy_c, dil, d), "wgrad_stream: workspace too small");
-  SEUNET_CHECK((long long)d.H * d.W * 32 * 2 < (1LL << 31), "wgrad_stream: plane exceeds the 32-bit offsets of this kernel");
+  SEUNET_CHECK((long long)d.D * d.H * d.W * (x_c > dy_c ? x_c : dy_c) * 2 < 0xFFFFFFFFll,
+               "wgrad_stream: one sample exceeds the 32-bit buffer offsets of this kernel");
   WsArgs a{};
-  a.x = x; a.dy = dy; a.slab = reinterpret_cast<float*>(workspace); a.zero = device_zero_page();
-  SEUNET_CHECK(a.zero != nullptr, "wgrad_stream: no zero page on this device");
+  a.x = x; a.dy = dy; a.slab = reinterpret_cast<float*>(workspace);
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const int planes = cdiv(d.D, dil);
   a.zsteps = ws_zsteps(d, dil);
