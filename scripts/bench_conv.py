@@ -85,15 +85,17 @@ for name, split, cout, dil, size in CASES:
         lib.seunet_debug_set_buffer.argtypes = [C.c_void_p]
         lib.seunet_debug_set_buffer(dbg.data_ptr())
         names = ["first-prefetch", "barrier1", "regwait+ldswrite", "barrier2", "prefetch-issue", "mfma-block", "bias+stats", "barrier-after-K", "index-plan", "xwave-stats", "stage-writes", "stage-reads+stores"]
+        if os.environ.get("SEUNET_STAMP") == "stream":     # (a -DSEUNET_STAMP build of conv_stream.hip)
+            names = ["prologue", "plane-wait", "barrier", "frag+dma+mfma-issue", "mfma-drain", "epilogue+stores"] + [""] * 6
         for nm, fn in (("fwd", fwd), ("dgrad", dgrad)):
-            if nm not in which:
+            if nm not in which or os.environ.get("SEUNET_STAMP") == "stream":
                 continue
             fn(); torch.cuda.synchronize(); dbg.zero_(); fn(); torch.cuda.synchronize()
             rec = dbg.view(-1, 12).double()
             used = rec.sum(1) > 0
             v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
             print("  stamps %s %s: " % (name, nm) + "  ".join("%s %.1f%%" % (names[i], 100 * float(v[i]) / tot) for i in range(12)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
-        if "wgrad" in which:
+        if "wgrad" in which and os.environ.get("SEUNET_STAMP") != "stream":
             wn = ["prologue", "barrier1", "dma-issue", "dma-land+barrier2", "mfma-rows", "slab-store"]
             wgrad(); torch.cuda.synchronize(); dbg.zero_(); wgrad(); torch.cuda.synchronize()
             rec = dbg.view(-1, 12).double()
@@ -137,6 +139,12 @@ for name, split, cout, dil, size in CASES:
             _lib.check(lib.seunet_conv3d_stream(code, dil, srcs[0].data_ptr(), cin, ws_.data_ptr(), sb.data_ptr(), out_s.data_ptr(), cout, 0,
                                                 sstats.data_ptr(), dims, _lib.stream_ptr()))
         ms = timeit(sfwd)
+        if os.environ.get("SEUNET_STAMP") == "stream":
+            sfwd(); torch.cuda.synchronize(); dbg.zero_(); sfwd(); torch.cuda.synchronize()
+            rec = dbg.view(-1, 12).double(); used = rec.sum(1) > 0
+            v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
+            sn = ["prologue", "plane-wait", "barrier", "frag+dma+mfma-issue", "mfma-drain", "epilogue-rest", "stats", "pack+store-issue"]
+            print("  stamps %s STREAM fwd: " % name + "  ".join("%s %.1f%%" % (sn[i], 100 * float(v[i]) / tot) for i in range(8)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
         res.append("STREAM fwd %.3f ms %.0f TF/s" % (ms, flops / ms / 1e9))
     if TAPS == 27 and len(split) == 1 and lib.seunet_conv3d_stream_supported(code, dil, cout, cin) and "dgrad" in which:
         wd_ = torch.empty(lib.seunet_conv3d_stream_wpack_bytes(cout), dtype=torch.uint8, device="cuda")
@@ -146,5 +154,11 @@ for name, split, cout, dil, size in CASES:
             _lib.check(lib.seunet_conv3d_stream(code, dil, dy.data_ptr(), cout, wd_.data_ptr(), None, g_s.data_ptr(), cin, 1,
                                                 None, dims, _lib.stream_ptr()))
         ms = timeit(sdgrad)
+        if os.environ.get("SEUNET_STAMP") == "stream":
+            sdgrad(); torch.cuda.synchronize(); dbg.zero_(); sdgrad(); torch.cuda.synchronize()
+            rec = dbg.view(-1, 12).double(); used = rec.sum(1) > 0
+            v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
+            sn = ["prologue", "plane-wait", "barrier", "frag+dma+mfma-issue", "mfma-drain", "epilogue-rest", "stats", "pack+store-issue"]
+            print("  stamps %s STREAM dgrad: " % name + "  ".join("%s %.1f%%" % (sn[i], 100 * float(v[i]) / tot) for i in range(8)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
         res.append("STREAM dgrad+= %.3f ms %.0f TF/s" % (ms, flops / ms / 1e9))
     print("%-4s %s->%d d%d @%d^3 B%d: " % (name, split, cout, dil, size, B) + " | ".join(res), flush=True)

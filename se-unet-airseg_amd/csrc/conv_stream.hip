@@ -30,6 +30,8 @@
 
 namespace seunet {
 
+extern unsigned long long* g_conv_debug;   // conv_igemm.hip (diagnostic builds)
+
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -49,6 +51,7 @@ struct StreamArgs {
   const void* src; const void* wpack; const float* bias;
   void* dst; int dstC; int dacc; int cout;
   double* stats; const void* zero;
+  unsigned long long* debug;       // diagnostic builds only (-DSEUNET_STAMP): [workgroup][wave][12] cycle sums per phase
   int N, D, H, W;
   int nyb, nxb, nzseg, zsteps;      // patches, z segments (per parity class), output planes per segment
 };
@@ -95,15 +98,28 @@ __device__ __forceinline__ void stream_dma16_buf(unsigned voff, u32x4s rsrc, uns
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
 }
+// -DSEUNET_STREAM_PROBE=1: no statistics; 2: no stores; 3: no MFMAs; 4: no fragment reads (timing by elimination, never shipped)
+#ifndef SEUNET_STREAM_PROBE
+#define SEUNET_STREAM_PROBE 0
+#endif
+#ifdef SEUNET_STAMP
+#define SSTAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); ph[i] += _t - t_last; t_last = _t; } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
 template <int N> __device__ __forceinline__ void stream_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // FWD: bias + InstanceNorm partial sums (forward); !FWD: data gradient, optionally accumulating into the destination (DACC)
 template <typename T, int CIN, int COUTP, bool XFOLD, int DIL, bool FWD, bool DACC>
 __global__ void __launch_bounds__(ST_NW * 64, 2)
 conv_stream_kernel(StreamArgs a) {
+#ifdef SEUNET_STAMP
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
   using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL, DACC>;
-  constexpr int NP = Geo::NP, HX = Geo::HX, HY = Geo::HY, NVP = Geo::NVP, G = Geo::G, PS = Geo::PS, PLANE = Geo::PLANE;
-  constexpr int ITEMS = Geo::ITEMS, NB = Geo::NB, NBX = Geo::NBX, NDX = Geo::NDX, NTAP = Geo::NTAP, STORES = Geo::STORES;
+  constexpr int NP = Geo::NP, HX = Geo::HX, NVP = Geo::NVP, G = Geo::G, PS = Geo::PS, PLANE = Geo::PLANE;
+  constexpr int ITEMS = Geo::ITEMS, NB = Geo::NB, NBX = Geo::NBX, NDX = Geo::NDX, NTAP = Geo::NTAP;
   constexpr int ACCR = COUTP == 32 ? 16 : 4;
   typedef typename std::conditional<COUTP == 32, f32x16, f32x4>::type AccT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -256,6 +272,12 @@ conv_stream_kernel(StreamArgs a) {
   const int dst_plane = __builtin_amdgcn_readfirstlane(a.H * a.W * a.dstC * (int)sizeof(T));
   bool okl[NBX];
   unsigned lofs[NBX][ACCR / 4];
+  unsigned wofs[NBX][2];                                           // 32-channel tiles, 16-byte stores: channels 16 j + 8 * (lane >> 5) ..+7
+#ifdef SEUNET_STREAM_NARROW
+  const bool wide = false;
+#else
+  const bool wide = COUTP == 32 && a.cout % 8 == 0 && a.dstC % 8 == 0;   // wave-uniform
+#endif
 #pragma unroll
   for (int b = 0; b < NBX; ++b) {
     const int y = y0 + ra, x = x0 + b * NB + fn;
@@ -264,6 +286,11 @@ conv_stream_kernel(StreamArgs a) {
     for (int pc = 0; pc < ACCR / 4; ++pc) {
       const int c0 = chan(4 * pc);
       lofs[b][pc] = (okl[b] && c0 < a.cout) ? (unsigned)(((y * a.W + x) * a.dstC + c0) * (int)sizeof(T)) : 0x80000000u;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c0 = 16 * j + 8 * fg;
+      wofs[b][j] = (okl[b] && c0 < a.cout) ? (unsigned)(((y * a.W + x) * a.dstC + c0) * (int)sizeof(T)) : 0x80000000u;
     }
   }
 
@@ -283,7 +310,8 @@ conv_stream_kernel(StreamArgs a) {
 #pragma unroll
           for (int b = 0; b < NBX; ++b) {
             const int off = frag0 + ((DIL * ri) * HX + b * NB + DIL * Geo::VPK * dxi) * 16;
-            fr[ri & 1][dxi][b] = *reinterpret_cast<const bf16x8*>(pl + off);
+            if constexpr (SEUNET_STREAM_PROBE == 4) fr[ri & 1][dxi][b] = wreg[(ri * NDX + dxi) % NTAP];
+            else fr[ri & 1][dxi][b] = *reinterpret_cast<const bf16x8*>(pl + off);
           }
       }
     };
@@ -320,7 +348,10 @@ conv_stream_kernel(StreamArgs a) {
             const bool first = dz == -1 && ri == 0 && dxi == 0;
 #pragma unroll
             for (int b = 0; b < NBX; ++b) {
-              if constexpr (COUTP == 32) acc[ai][b] = st_mfma32<T>(wreg[tap], fr[ri & 1][dxi][b], first ? cinit : acc[ai][b]);
+              if constexpr (SEUNET_STREAM_PROBE == 3) {
+                if (first) acc[ai][b] = cinit;
+                acc[ai][b][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4s, fr[ri & 1][dxi][b]).x);   // (keeps the reads alive)
+              } else if constexpr (COUTP == 32) acc[ai][b] = st_mfma32<T>(wreg[tap], fr[ri & 1][dxi][b], first ? cinit : acc[ai][b]);
               else acc[ai][b] = st_mfma16<T>(wreg[tap], fr[ri & 1][dxi][b], first ? cinit : acc[ai][b]);
             }
           }
@@ -343,13 +374,19 @@ conv_stream_kernel(StreamArgs a) {
       float v[ACCR];
 #pragma unroll
       for (int e = 0; e < ACCR; ++e) v[e] = acc[ai][b][e];       // (bias included: it was the C operand of the set's first MFMA)
-      if constexpr (FWD) {
+      if constexpr (FWD && SEUNET_STREAM_PROBE != 1) {
         if (zok && okl[b]) {             // (a.stats == nullptr: the sums are simply never stored)
 #pragma unroll
           for (int e = 0; e < ACCR; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
         }
       }
+#ifdef SEUNET_STAMP
+#pragma unroll
+      for (int e = 0; e < SR; ++e) asm volatile("" : "+v"(s1[e]), "+v"(s2[e]));
+      SSTAMP(6);   // statistics
+#endif
       // runs of 4 consecutive channels -> 8-byte pieces
+      u32x2s u[ACCR / 4];
 #pragma unroll
       for (int pc = 0; pc < ACCR / 4; ++pc) {
         float w4[4] = {v[4 * pc], v[4 * pc + 1], v[4 * pc + 2], v[4 * pc + 3]};
@@ -360,25 +397,69 @@ conv_stream_kernel(StreamArgs a) {
           w4[0] += unpack_lo<T>(o.x); w4[1] += unpack_hi<T>(o.x);
           w4[2] += unpack_lo<T>(o.y); w4[3] += unpack_hi<T>(o.y);
         }
-        u32x2s u;
-        u.x = pack2<T>(w4[0], w4[1]);
-        u.y = pack2<T>(w4[2], w4[3]);
-        __builtin_amdgcn_raw_buffer_store_b64(u, rd, lofs[b][pc], soff, 0);
+        u[pc].x = pack2<T>(w4[0], w4[1]);
+        u[pc].y = pack2<T>(w4[2], w4[3]);
       }
+      if constexpr (COUTP == 32) {
+        // 32x32 tiles: lane n holds channels 8 pc .. 8 pc + 3 of its voxel, lane n + 32 channels 8 pc + 4 .. 8 pc + 7.  With all
+        // channels present (wide: cout a multiple of 16) a half-wave exchange per register (v_permlane32_swap: lanes 32..63 of
+        // the first operand <-> lanes 0..31 of the second) leaves 16 contiguous bytes per lane -- channels 16 j .. 16 j + 7 in the
+        // lower half, 16 j + 8 .. 16 j + 15 in the upper -- so a row goes out in 2 stores of 16 B per lane instead of 4 of 8 B:
+        // the tail is bound by store instructions, not bytes (round 4)
+        if (wide) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            u32x2s lo = u[2 * j], hi = u[2 * j + 1];
+            const auto rx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+            u32x4s q;      // lower half: own run | the upper lane's run of piece 2 j; upper half: the lower lane's run | own run of piece 2 j + 1
+            q.x = rx[0]; q.y = ry[0]; q.z = rx[1]; q.w = ry[1];
+            // (the exchange writes BOTH its operands; a store issued right behind it took stale bytes of the second one now and then --
+            // wrong output rows in about one launch configuration of 64 per test run; a few idle cycles tied to the four registers
+            // keep the store off the exchange's heels)
+            asm volatile("s_nop 3" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
+            if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(q));
+            else __builtin_amdgcn_raw_buffer_store_b128(q, rd, wofs[b][j], soff, 0);
+          }
+        } else {
+#pragma unroll
+          for (int pc = 0; pc < ACCR / 4; ++pc) {
+            if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(u[pc]));
+            else __builtin_amdgcn_raw_buffer_store_b64(u[pc], rd, lofs[b][pc], soff, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int pc = 0; pc < ACCR / 4; ++pc) {
+          if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(u[pc]));
+          else __builtin_amdgcn_raw_buffer_store_b64(u[pc], rd, lofs[b][pc], soff, 0);
+        }
+      }
+      SSTAMP(7);     // packing + store issue
     }
   };
 
   // ---- the march ----
   // VMEM issue order of a wave: [prologue: DMA(0) .. DMA(PF-1)]  then per step s: DMA(s+PF) (inside compute), stores(s).
-  // At the top of step s >= 1 plane s must have landed; younger than it are DMA(s+1) .. DMA(s+PF-1) and the stores of up to
-  // three steps: waiting for all but (PF-1) * LW + STORES operations is sufficient from step 1 on (and asks the stores of
-  // steps <= s-2, a full step old, to be done).  Then one barrier: every wave's part of the plane is in LDS, and every wave
-  // has finished reading the slot that this step's prefetch overwrites (ring = PF + 2 slots).
+  // At the top of step s >= 1 plane s must have landed; it was issued in step s - PF (or the prologue), and younger than it are
+  // DMA(s+1) .. DMA(s+PF-1) and the stores of min(s, PF) steps: waiting for all but (PF-1) * LW + min(s, PF) * (stores per step)
+  // operations is exactly sufficient (the first trip of the loop, s < 3, uses the count of s = 1; round 3 used that count for every
+  // step, which also waited for the NEXT plane and for the stores of two steps ago).  Then one barrier: every wave's part of the
+  // plane is in LDS, and every wave has finished reading the slot that this step's prefetch overwrites (ring = PF + 2 slots).
   constexpr int LW = ITEMS + (DACC ? Geo::OLDI : 0);   // DMA instructions per wave and step (padded to the same count in every wave)
+  constexpr int MINST = COUTP == 32 ? 2 : NBX;          // store instructions per wave and step, at least (32-channel tiles: 2 wide or 4 narrow)
 #pragma unroll
   for (int k = 0; k < Geo::PF; ++k) { dma_plane(k, k); dma_old(k, k); }
+  // The weight loads are ordinary (compiler-visible) loads, and the compiler waits for a load at its first use -- which is inside
+  // the march.  Where it does not peel the first step (the accumulating variants) it put `s_waitcnt vmcnt(4) / (1) / (0)` between the
+  // MFMAs of EVERY step: each step then drained the plane prefetch it had just issued (the counter is in issue order), i.e. the
+  // whole HBM latency was exposed per step (found in the ISA, round 4).  One use of every fragment here makes it wait once, before
+  // the march (it also drains the prologue's planes: a one-time cost).
+#pragma unroll
+  for (int k = 0; k < NTAP; ++k) asm volatile("" :: "v"(wreg[k]));
   stream_wait_vm<(Geo::PF - 1) * LW>();    // plane 0 has landed (this wave's part)
   __builtin_amdgcn_s_barrier();
+  SSTAMP(0);   // prologue: plans, weights, first planes
   int slot = 0, slot_pf = Geo::PF;         // s % Geo::RING, (s + Geo::PF) % Geo::RING
   for (int s0 = 0; s0 < nsteps; s0 += 3) {
     [&]<int... PH>(std::integer_sequence<int, PH...>) __attribute__((always_inline)) {
@@ -386,18 +467,30 @@ conv_stream_kernel(StreamArgs a) {
         const int s = s0 + PH;
         if (s < nsteps) {
           if (s > 0) {
-            stream_wait_vm<(Geo::PF - 1) * LW + STORES>();
+#ifdef SEUNET_STREAM_OLDWAIT
+            if (true) stream_wait_vm<(Geo::PF - 1) * LW + MINST>();
+#else
+            if (s0 == 0) stream_wait_vm<(Geo::PF - 1) * LW + MINST>();
+#endif
+            else stream_wait_vm<(Geo::PF - 1) * LW + Geo::PF * MINST>();
+            SSTAMP(1);   // counted wait for the plane (and the stores of two steps ago)
             __builtin_amdgcn_s_barrier();
+            SSTAMP(2);   // barrier
           }
           compute(s, slot, slot_pf, std::integral_constant<int, PH>{});
+          SSTAMP(3);     // fragment reads, DMA issue, MFMA issue
+#ifdef SEUNET_STAMP
+          asm volatile("v_mov_b32 %0, %0" : "+v"(acc[(PH + 2) % 3][NBX - 1][ACCR - 1]));
+          SSTAMP(4);     // the finished set's last MFMA has written its result
+#endif
           finish(s, slot, std::integral_constant<int, PH>{});
+          SSTAMP(5);     // epilogue: sums, packing, store issue
           slot = slot == Geo::RING - 1 ? 0 : slot + 1;
           slot_pf = slot_pf == Geo::RING - 1 ? 0 : slot_pf + 1;
         }
       }(), ...);
     }(std::make_integer_sequence<int, 3>{});
   }
-
   // ---- InstanceNorm partial sums of this workgroup: un-shift in f64, reduce over the lanes that hold the same channels,
   //      then over the four waves (fixed order), one record per workgroup ----
   if (FWD && a.stats != nullptr) {
@@ -432,6 +525,13 @@ conv_stream_kernel(StreamArgs a) {
   } else {
     stream_wait_vm<0>();         // no DMA may outlive the workgroup's LDS allocation
   }
+#ifdef SEUNET_STAMP
+  if (a.debug != nullptr && lane == 0) {
+    const size_t w = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ST_NW + wave;
+    for (int i = 0; i < 8; ++i) a.debug[w * 12 + i] = ph[i];
+    for (int i = 8; i < 12; ++i) a.debug[w * 12 + i] = 0;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -543,6 +643,7 @@ int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const voi
   StreamArgs a{};
   a.src = src; a.wpack = wpack; a.bias = bias; a.dst = dst; a.dstC = dst_c; a.dacc = dst_accumulate; a.cout = dst_c;
   a.stats = stats; a.zero = device_zero_page();
+  a.debug = g_conv_debug;
   SEUNET_CHECK(a.zero != nullptr, "conv_stream: no zero page on this device");
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const int planes = cdiv(d.D, dil);
