@@ -143,8 +143,8 @@ for name, split, cout, dil, size in CASES:
             sfwd(); torch.cuda.synchronize(); dbg.zero_(); sfwd(); torch.cuda.synchronize()
             rec = dbg.view(-1, 12).double(); used = rec.sum(1) > 0
             v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
-            sn = ["prologue", "plane-wait", "barrier", "frag+dma+mfma-issue", "mfma-drain", "epilogue-rest", "stats", "pack+store-issue"]
-            print("  stamps %s STREAM fwd: " % name + "  ".join("%s %.1f%%" % (sn[i], 100 * float(v[i]) / tot) for i in range(8)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
+            sn = ["first-plane-wait+barrier", "plane-wait", "barrier", "frag+dma+mfma-issue", "mfma-drain", "epilogue-rest", "stats", "pack+store-issue", "pro:plan", "pro:weights+geometry", "pro:dma-issue+weight-wait", ""]
+            print("  stamps %s STREAM fwd: " % name + "  ".join("%s %.1f%%" % (sn[i], 100 * float(v[i]) / tot) for i in range(11)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
         res.append("STREAM fwd %.3f ms %.0f TF/s" % (ms, flops / ms / 1e9))
     if TAPS == 27 and len(split) == 1 and lib.seunet_conv3d_stream_supported(code, dil, cout, cin) and "dgrad" in which:
         wd_ = torch.empty(lib.seunet_conv3d_stream_wpack_bytes(cout), dtype=torch.uint8, device="cuda")
@@ -158,7 +158,7 @@ for name, split, cout, dil, size in CASES:
             sdgrad(); torch.cuda.synchronize(); dbg.zero_(); sdgrad(); torch.cuda.synchronize()
             rec = dbg.view(-1, 12).double(); used = rec.sum(1) > 0
             v = rec[used].sum(0).cpu(); nw = int(used.sum()); tot = float(v.sum())
-            sn = ["prologue", "plane-wait", "barrier", "frag+dma+mfma-issue", "mfma-drain", "epilogue-rest", "stats", "pack+store-issue"]
-            print("  stamps %s STREAM dgrad: " % name + "  ".join("%s %.1f%%" % (sn[i], 100 * float(v[i]) / tot) for i in range(8)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
+            sn = ["first-plane-wait+barrier", "plane-wait", "barrier", "frag+dma+mfma-issue", "mfma-drain", "epilogue-rest", "stats", "pack+store-issue", "pro:plan", "pro:weights+geometry", "pro:dma-issue+weight-wait", ""]
+            print("  stamps %s STREAM dgrad: " % name + "  ".join("%s %.1f%%" % (sn[i], 100 * float(v[i]) / tot) for i in range(11)) + "  (waves %d, cycles/wave %.0f)" % (nw, tot / nw), flush=True)
         res.append("STREAM dgrad+= %.3f ms %.0f TF/s" % (ms, flops / ms / 1e9))
     print("%-4s %s->%d d%d @%d^3 B%d: " % (name, split, cout, dil, size, B) + " | ".join(res), flush=True)

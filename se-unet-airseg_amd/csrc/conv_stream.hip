@@ -114,7 +114,7 @@ template <typename T, int CIN, int COUTP, bool XFOLD, int DIL, bool FWD, bool DA
 __global__ void __launch_bounds__(ST_NW * 64, 2)
 conv_stream_kernel(StreamArgs a) {
 #ifdef SEUNET_STAMP
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_readcyclecounter();
 #endif
   using Geo = StreamGeo<CIN, COUTP, XFOLD, DIL, DACC>;
@@ -158,6 +158,7 @@ conv_stream_kernel(StreamArgs a) {
     doff[it] = ok ? (unsigned)(((y * a.W + x) * CIN + p * 8) * (int)sizeof(T)) : 0xFFFFFFFFu;
     dlds[it] = (unsigned)(p * PS + gi * 1024);
   }
+  SSTAMP(8);       // (prologue) DMA plan
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(a.zero) + lane * 16;     // (old destination rows only)
   // source descriptor of this sample: base (scalar registers), num_records = the sample's bytes (0 for a plane outside the volume)
   unsigned src_lo, src_hi;
@@ -294,6 +295,10 @@ conv_stream_kernel(StreamArgs a) {
     }
   }
 
+  SSTAMP(9);       // (prologue) weight loads issued, fragment / store geometry
+  float mk[NBX];
+#pragma unroll
+  for (int b = 0; b < NBX; ++b) mk[b] = okl[b] ? 1.f : 0.f;
   // ---- one step: input plane of step s (ring slot `slot`) -> accumulators; PH = s % 3 ----
   // The fragments of input row ri + 1 are requested before the MFMAs of row ri issue (two register sets), and the prefetch
   // DMA instructions of the plane Geo::PF steps ahead are spread over the rows.
@@ -375,10 +380,11 @@ conv_stream_kernel(StreamArgs a) {
 #pragma unroll
       for (int e = 0; e < ACCR; ++e) v[e] = acc[ai][b][e];       // (bias included: it was the C operand of the set's first MFMA)
       if constexpr (FWD && SEUNET_STREAM_PROBE != 1) {
-        if (zok && okl[b]) {             // (a.stats == nullptr: the sums are simply never stored)
+        // branch-free (a lane outside the volume or a plane outside the march adds v * 0; a.stats == nullptr: the sums are simply
+        // never stored): fma(v, 1, s) and fma(v * 1, v, s) round exactly like s + v and fma(v, v, s)
+        const float m = zok ? mk[b] : 0.f;
 #pragma unroll
-          for (int e = 0; e < ACCR; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
-        }
+        for (int e = 0; e < ACCR; ++e) { s1[e] = fmaf(v[e], m, s1[e]); s2[e] = fmaf(v[e] * m, v[e], s2[e]); }
       }
 #ifdef SEUNET_STAMP
 #pragma unroll
@@ -457,6 +463,7 @@ conv_stream_kernel(StreamArgs a) {
   // the march (it also drains the prologue's planes: a one-time cost).
 #pragma unroll
   for (int k = 0; k < NTAP; ++k) asm volatile("" :: "v"(wreg[k]));
+  SSTAMP(10);      // (prologue) first planes requested, weights arrived
   stream_wait_vm<(Geo::PF - 1) * LW>();    // plane 0 has landed (this wave's part)
   __builtin_amdgcn_s_barrier();
   SSTAMP(0);   // prologue: plans, weights, first planes
@@ -528,8 +535,7 @@ conv_stream_kernel(StreamArgs a) {
 #ifdef SEUNET_STAMP
   if (a.debug != nullptr && lane == 0) {
     const size_t w = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ST_NW + wave;
-    for (int i = 0; i < 8; ++i) a.debug[w * 12 + i] = ph[i];
-    for (int i = 8; i < 12; ++i) a.debug[w * 12 + i] = 0;
+    for (int i = 0; i < 12; ++i) a.debug[w * 12 + i] = ph[i];
   }
 #endif
 }
