@@ -273,12 +273,6 @@ conv_stream_kernel(StreamArgs a) {
   const int dst_plane = __builtin_amdgcn_readfirstlane(a.H * a.W * a.dstC * (int)sizeof(T));
   bool okl[NBX];
   unsigned lofs[NBX][ACCR / 4];
-  unsigned wofs[NBX][2];                                           // 32-channel tiles, 16-byte stores: channels 16 j + 8 * (lane >> 5) ..+7
-#ifdef SEUNET_STREAM_NARROW
-  const bool wide = false;
-#else
-  const bool wide = COUTP == 32 && a.cout % 8 == 0 && a.dstC % 8 == 0;   // wave-uniform
-#endif
 #pragma unroll
   for (int b = 0; b < NBX; ++b) {
     const int y = y0 + ra, x = x0 + b * NB + fn;
@@ -287,11 +281,6 @@ conv_stream_kernel(StreamArgs a) {
     for (int pc = 0; pc < ACCR / 4; ++pc) {
       const int c0 = chan(4 * pc);
       lofs[b][pc] = (okl[b] && c0 < a.cout) ? (unsigned)(((y * a.W + x) * a.dstC + c0) * (int)sizeof(T)) : 0x80000000u;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c0 = 16 * j + 8 * fg;
-      wofs[b][j] = (okl[b] && c0 < a.cout) ? (unsigned)(((y * a.W + x) * a.dstC + c0) * (int)sizeof(T)) : 0x80000000u;
     }
   }
 
@@ -406,40 +395,14 @@ conv_stream_kernel(StreamArgs a) {
         u[pc].x = pack2<T>(w4[0], w4[1]);
         u[pc].y = pack2<T>(w4[2], w4[3]);
       }
-      if constexpr (COUTP == 32) {
-        // 32x32 tiles: lane n holds channels 8 pc .. 8 pc + 3 of its voxel, lane n + 32 channels 8 pc + 4 .. 8 pc + 7.  With all
-        // channels present (wide: cout a multiple of 16) a half-wave exchange per register (v_permlane32_swap: lanes 32..63 of
-        // the first operand <-> lanes 0..31 of the second) leaves 16 contiguous bytes per lane -- channels 16 j .. 16 j + 7 in the
-        // lower half, 16 j + 8 .. 16 j + 15 in the upper -- so a row goes out in 2 stores of 16 B per lane instead of 4 of 8 B:
-        // the tail is bound by store instructions, not bytes (round 4)
-        if (wide) {
+      // (Round 4 tried 16-byte stores for the 32-channel tiles -- a half-wave exchange, v_permlane32_swap, pairs the 8-byte runs of
+      // lanes n and n + 32: 2 stores per row instead of 4, ec3 forward 0.302 -> 0.268 ms -- and took it out again: about one launch
+      // in a hundred wrote wrong rows, with the builtin and with the exchange in an asm block padded by idle cycles on both sides
+      // alike; the 8-byte form has never shown it.  DESIGN 4.)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            u32x2s lo = u[2 * j], hi = u[2 * j + 1];
-            const auto rx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
-            const auto ry = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
-            u32x4s q;      // lower half: own run | the upper lane's run of piece 2 j; upper half: the lower lane's run | own run of piece 2 j + 1
-            q.x = rx[0]; q.y = ry[0]; q.z = rx[1]; q.w = ry[1];
-            // (the exchange writes BOTH its operands; a store issued right behind it took stale bytes of the second one now and then --
-            // wrong output rows in about one launch configuration of 64 per test run; a few idle cycles tied to the four registers
-            // keep the store off the exchange's heels)
-            asm volatile("s_nop 3" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
-            if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(q));
-            else __builtin_amdgcn_raw_buffer_store_b128(q, rd, wofs[b][j], soff, 0);
-          }
-        } else {
-#pragma unroll
-          for (int pc = 0; pc < ACCR / 4; ++pc) {
-            if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(u[pc]));
-            else __builtin_amdgcn_raw_buffer_store_b64(u[pc], rd, lofs[b][pc], soff, 0);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int pc = 0; pc < ACCR / 4; ++pc) {
-          if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(u[pc]));
-          else __builtin_amdgcn_raw_buffer_store_b64(u[pc], rd, lofs[b][pc], soff, 0);
-        }
+      for (int pc = 0; pc < ACCR / 4; ++pc) {
+        if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(u[pc]));
+        else __builtin_amdgcn_raw_buffer_store_b64(u[pc], rd, lofs[b][pc], soff, 0);
       }
       SSTAMP(7);     // packing + store issue
     }
@@ -453,7 +416,7 @@ conv_stream_kernel(StreamArgs a) {
   // step, which also waited for the NEXT plane and for the stores of two steps ago).  Then one barrier: every wave's part of the
   // plane is in LDS, and every wave has finished reading the slot that this step's prefetch overwrites (ring = PF + 2 slots).
   constexpr int LW = ITEMS + (DACC ? Geo::OLDI : 0);   // DMA instructions per wave and step (padded to the same count in every wave)
-  constexpr int MINST = COUTP == 32 ? 2 : NBX;          // store instructions per wave and step, at least (32-channel tiles: 2 wide or 4 narrow)
+  constexpr int MINST = Geo::STORES;                    // store instructions per wave and step
 #pragma unroll
   for (int k = 0; k < Geo::PF; ++k) { dma_plane(k, k); dma_old(k, k); }
   // The weight loads are ordinary (compiler-visible) loads, and the compiler waits for a load at its first use -- which is inside
