@@ -183,7 +183,10 @@ struct Plan {
     for (int t = 0; t < T_COUNT; ++t) {
       const size_t bytes = (size_t)d.batch * dims[kT[t].level].vox() * C[t] * esz;
       if (!placed[t]) { feat[t] = take(bytes); placed[t] = true; }
-      const int mate = t == T_E1 ? T_D2U : t == T_E3 ? T_D1U : t == T_E5 ? T_E8 : -1;   // (dc5, dc3, dc1: skip next to up-sampled)
+      // (dc5 only.  The same placement for dc3 and dc1 cost their tiled forward 5 % -- conv_fwd:dc3 0.465 -> 0.49 ms, same box,
+      // alternating runs -- and their sources are 1.2 GB apart at batch 4 anyway; beyond 4 GB the weight gradient of those two
+      // layers takes the tiled kernel)
+      const int mate = t == T_E1 ? T_D2U : -1;
       if (mate >= 0 && !placed[mate]) {
         feat[mate] = take((size_t)d.batch * dims[kT[mate].level].vox() * C[mate] * esz);
         placed[mate] = true;
