@@ -315,12 +315,13 @@ upsample2_fwd_march_kernel(const T* __restrict__ in, int C, T* __restrict__ out,
   T* tile = reinterpret_cast<T*>(ufm_raw);                     // [2 buffers][3 coarse rows][UFM_XC][C]
   const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
   const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
-  const int xf0 = blockIdx.x * XF;
+  const TileIdx3 tl = xcd_contiguous_tile3();                  // (round 4: neighbouring tiles on one XCD, the halo in one L2)
+  const int xf0 = tl.x * XF;
   const int nxf = (Wo - xf0 < XF) ? Wo - xf0 : XF;
-  const int yb = blockIdx.y;
+  const int yb = tl.y;
   const int nseg = (Do + UFM_ZSF - 1) / UFM_ZSF;
-  const int seg = blockIdx.z % nseg;
-  const long long n = blockIdx.z / nseg;
+  const int seg = tl.z % nseg;
+  const long long n = tl.z / nseg;
   const int zf_a = seg * UFM_ZSF, zf_b = zf_a + UFM_ZSF < Do ? zf_a + UFM_ZSF : Do;
   int i0, i1; float lam;
   // coarse rows / columns under the block
@@ -586,10 +587,11 @@ upsample2_bwd_march_kernel(const T* __restrict__ g_out, int C, T* g_in, int accu
   __shared__ int yls[TY], nys[TY];
   const int G = C / 8, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
   const float rz = ac_scale(D, Do), ry = ac_scale(H, Ho), rx = ac_scale(W, Wo);
-  const int x0 = blockIdx.x * UM_TX, y0 = blockIdx.y * TY;
+  const TileIdx3 tl = xcd_contiguous_tile3();                  // (round 4: neighbouring tiles on one XCD, the halo in one L2)
+  const int x0 = tl.x * UM_TX, y0 = tl.y * TY;
   const int nseg = (D + ZS - 1) / ZS;
-  const int seg = blockIdx.z % nseg;
-  const long long n = blockIdx.z / nseg;
+  const int seg = tl.z % nseg;
+  const long long n = tl.z / nseg;
   const int zc0 = seg * ZS, zc1 = zc0 + ZS < D ? zc0 + ZS : D;
   const int x1 = (x0 + UM_TX < W ? x0 + UM_TX : W) - 1;
   int i0, i1; float lam;

@@ -190,6 +190,23 @@ __device__ __forceinline__ void zero8p(Pack8<float>& k) { k.a = k.b = make_float
 // nothing.  `dpp_settle` makes a value that came through DPP the operand of a plain vector move: the move cannot issue before the
 // DPP instruction has completed, and a scalar write of EXEC behind it is ordered after it by the ordinary interlock.  Every
 // reduction that ends in DPP passes its result through it.
+// Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), and each XCD has its own L2.  Kernels whose
+// neighbouring tiles share halo data re-number their tiles so that an XCD works on a contiguous run of them (tile t of `nt`
+// for launch-order index b): the halo is then fetched into one L2 instead of several.
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int nt) {
+  const int q = nt >> 3, r = nt & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+struct TileIdx3 { int x, y, z; };
+__device__ __forceinline__ TileIdx3 xcd_contiguous_tile3() {   // the 3-D grid form: (x, y, z) of this workgroup's tile, x fastest
+  const int b = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int t = xcd_contiguous_tile(b, (int)(gridDim.x * gridDim.y * gridDim.z));
+  TileIdx3 r;
+  r.x = t % (int)gridDim.x;
+  r.y = (t / (int)gridDim.x) % (int)gridDim.y;
+  r.z = t / (int)(gridDim.x * gridDim.y);
+  return r;
+}
 __device__ __forceinline__ float dpp_settle(float v) {
   asm volatile("v_mov_b32 %0, %0" : "+v"(v));
   return v;
