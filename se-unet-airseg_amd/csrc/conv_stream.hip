@@ -547,16 +547,28 @@ bool conv_stream_supported(int dtype, int taps, int dil, int src_c, int dst_c) {
 
 size_t conv_stream_wpack_bytes(int src_c) { return (size_t)27 * 64 * 16; (void)src_c; }
 
-static int stream_zsteps(int planes) {
-  // output planes per workgroup: long marches amortise the 2-plane pipeline fill; 1/3 .. 1/4 of the axis keeps >= 1000
-  // workgroups in flight on a 4 x 128^3 batch.  (zsteps + 2) % 3 == 0 wastes no unrolled step.
-  if (planes <= 40) return planes;
-  const int segs = (planes + 33) / 34;
-  return (planes + segs - 1) / segs;
+static int stream_zsteps(Dims d, int dil) {
+  // Output planes per workgroup.  Every workgroup pays a prologue (plan, weights, first planes: 8 % of a wave's time at 34 steps,
+  // round-4 stamps) and two halo steps, and the kernels with more than 128 registers per lane (every variant but the 8-channel
+  // one) have ONE workgroup resident per CU, so nothing hides them: the march is as long as the volume allows while a batch of
+  // FOUR samples still gives every CU a workgroup (measured at 1024, 512 and 256 workgroups per launch on 4 x 128^3: ec3 forward
+  // 0.308 / 0.282 / 0.274 ms, dc6 forward 0.219 / 0.204 / 0.190, ec2 forward 0.091 / 0.090 / 0.082 -- also for the 8-channel
+  // variants).  Round 3 cut the axis into 32-plane marches (1024 workgroups of 34 steps on that batch); this gives 256 of 130
+  // at dilation 1, 512 of 66 at dilation 2.  At least 8 planes per march.  The split is a function of the SAMPLE's extents only:
+  // the statistics records, hence the bits of a sample's result, must not depend on the batch it sits in (the data-parallel
+  // equivalence tests and the window loop rely on that), so a batch of one 128^3 sample fills a quarter of the chip here.
+  static const int target = [] { const char* e = std::getenv("SEUNET_STREAM_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int planes = cdiv(d.D, dil);
+  const long long base = (long long)cdiv(d.H, ST_TY) * cdiv(d.W, ST_TX) * dil * 4;
+  long long segs = (target + base - 1) / base;
+  const int cap = cdiv(planes, 8);
+  if (segs > cap) segs = cap;
+  if (segs < 1) segs = 1;
+  return cdiv(planes, (int)segs);
 }
 int conv_stream_slots(Dims d, int dil) {
   const int planes = cdiv(d.D, dil);
-  const int zs = stream_zsteps(planes);
+  const int zs = stream_zsteps(d, dil);
   return cdiv(d.H, ST_TY) * cdiv(d.W, ST_TX) * cdiv(planes, zs) * dil;
 }
 
@@ -616,7 +628,7 @@ int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const voi
   SEUNET_CHECK(a.zero != nullptr, "conv_stream: no zero page on this device");
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const int planes = cdiv(d.D, dil);
-  a.zsteps = stream_zsteps(planes);
+  a.zsteps = stream_zsteps(d, dil);
   a.nzseg = cdiv(planes, a.zsteps);
   a.nyb = cdiv(d.H, ST_TY); a.nxb = cdiv(d.W, ST_TX);
   SEUNET_CHECK(d.N <= 65535 && a.nzseg * dil <= 65535, "conv_stream: grid too large");
