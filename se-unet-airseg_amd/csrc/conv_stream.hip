@@ -258,7 +258,7 @@ conv_stream_kernel(StreamArgs a) {
     if (tid < 32) reinterpret_cast<float*>(smem + Geo::BIAS)[tid] = (a.bias != nullptr && tid < a.cout) ? a.bias[tid] : 0.f;
     __syncthreads();
   }
-  // running InstanceNorm sums of this lane (f32: at most ~40 values per lane and channel; the per-lane totals are combined in
+  // running InstanceNorm sums of this lane (f32: one value per plane of the march, at most ~130 per lane and channel at 128^3; the per-lane totals are combined in
   // f64.  bf16 activations keep 8 mantissa bits, the gate for this mode is the bf16-autocast comparison)
   float s1[SR], s2[SR];
 #pragma unroll
