@@ -49,7 +49,7 @@ template <typename T> __device__ __forceinline__ f32x4 st_mfma16(bf16x8 a, bf16x
 
 struct StreamArgs {
   const void* src; const void* wpack; const float* bias;
-  void* dst; int dstC; int dacc; int cout;
+  void* dst; int dstC; int dacc; int cout; int stage;
   double* stats; const void* zero;
   unsigned long long* debug;       // diagnostic builds only (-DSEUNET_STAMP): [workgroup][wave][12] cycle sums per phase
   int N, D, H, W;
@@ -71,13 +71,15 @@ template <int CIN, int COUTP, bool XFOLD, int DIL, bool DACC = false> struct Str
   static constexpr int OLDI = COUTP == 32 ? 2 : 1;             // DMA instructions per old destination row (32 voxels x <= 32 channels x 2 B <= 2 KB)
   // planes in flight ahead of the one being read: 3 where the 160 KB of LDS allow it; ring = those + the current one + the one
   // released by the previous step
-  static constexpr int PF = (5 * PLANE + 1280 + (DACC ? 5 * ST_NW * OLDI * 1024 : 0) <= 160 * 1024) ? 3 : 2;
+  static constexpr int STG = COUTP == 32 ? 2048 : 0;           // output row staging per wave (32-channel tiles: 32 voxels x 64 B)
+  static constexpr int PF = (5 * PLANE + 1280 + ST_NW * STG + (DACC ? 5 * ST_NW * OLDI * 1024 : 0) <= 160 * 1024) ? 3 : 2;
   static constexpr int RING = PF + 2;
   static constexpr int ITEMS = (NP * G + ST_NW - 1) / ST_NW;     // DMA wave-instructions per wave and plane
   static constexpr int NB = COUTP == 32 ? 32 : 16, NBX = ST_TX / NB;
-  static constexpr int STORES = COUTP == 32 ? 4 : NBX;           // store wave-instructions per wave and step
+  static constexpr int STORES = COUTP == 32 ? 4 : NBX;           // store wave-instructions per wave and step (direct and staged form alike)
   static constexpr int BIAS = RING * PLANE + 1024;          // f32 bias table (32-channel tiles keep it here instead of 16 registers per lane)
-  static constexpr int OLD = BIAS + 256;                       // old destination rows (gradient accumulation): [ring slots][8 waves][OLDI KB]
+  static constexpr int STAGE = BIAS + 256;                     // output rows on their way out: [8 waves][STG]
+  static constexpr int OLD = STAGE + ST_NW * STG;              // old destination rows (gradient accumulation): [ring slots][8 waves][OLDI KB]
   static constexpr int LDS = OLD + (DACC ? RING * ST_NW * OLDI * 1024 : 0);   // ring + a 1-KB dump for the padding DMA instructions (+ old rows)
 };
 
@@ -284,6 +286,40 @@ conv_stream_kernel(StreamArgs a) {
     }
   }
 
+  // Staged stores (round 4), 32-channel tiles.  A lane of an MFMA tile owns one voxel and runs of 4 channels, so its natural store is
+  // 8 bytes at a stride of one 64-byte voxel record: 64 different segments per store instruction, which the address path of the
+  // CU takes one by one -- timing by elimination put 0.085 ms of the 0.31 ms of the ec3 forward on the stores.  When the
+  // destination holds exactly 32 channels the finished row (32 voxels x 64 B = 2 KB, contiguous in memory) goes through a
+  // wave-private LDS buffer instead: 8-byte writes in the tile's layout (16-byte slots XOR-swizzled by the voxel number, so that
+  // every bank pair takes 4 lanes), 8-byte reads in memory order, four stores of 512 contiguous bytes.  ec3 forward 0.299 ->
+  // 0.255 ms, dc6 data gradient 0.32 -> 0.294.  (The 16-channel tiles keep the direct form: their records are 32 bytes, one
+  // instruction already covers 512 dense bytes, and staging cost them 10 %.  16-byte stores -- two per row -- would halve the
+  // instruction count again, and BOTH ways of forming them wrote wrong rows in about one launch of a hundred: from registers after a
+  // v_permlane32_swap exchange, and from this LDS buffer with ds_read_b128; the 8-byte form of the same staging never has.  It is
+  // buffer_store_dwordx4 next to the LDS-DMA traffic of this kernel that misbehaves, not the exchange; not understood.)
+  const bool staged = COUTP == 32 && a.stage != 0 && a.dstC == COUTP && a.cout == COUTP;         // wave-uniform
+  constexpr int NSTG = COUTP == 32 ? 4 : 2;          // 8-byte pieces per lane of the row image (16-byte stores: see finish())
+  const unsigned stg_base = (unsigned)(Geo::STAGE + wave * Geo::STG);
+  unsigned stg_w[NBX][ACCR / 4];      // LDS byte address of the lane's 8-byte pieces
+  unsigned stg_r[NSTG];               // LDS byte address of the lane's 16 bytes of the row image
+  unsigned stg_o[NSTG];               // their offset inside a destination plane (0x80000000: outside the volume)
+#pragma unroll
+  for (int b = 0; b < NBX; ++b)
+#pragma unroll
+    for (int pc = 0; pc < ACCR / 4; ++pc) {
+      const int v = b * NB + fn;
+      if constexpr (COUTP == 32) stg_w[b][pc] = stg_base + (unsigned)(v * 64 + 16 * (pc ^ ((v >> 1) & 3)) + 8 * fg);
+      else stg_w[b][pc] = stg_base + (unsigned)(v * 32 + 8 * fg);
+    }
+#pragma unroll
+  for (int k = 0; k < NSTG; ++k) {
+    const int g = k * 512 + lane * 8;                             // byte of the row image
+    const int v = g / (COUTP * 2);
+    if constexpr (COUTP == 32) stg_r[k] = stg_base + (unsigned)(v * 64 + 16 * (((g >> 4) & 3) ^ ((v >> 1) & 3)) + (g & 8));
+    else stg_r[k] = stg_base + (unsigned)g;
+    const int y = y0 + ra, x = x0 + v;
+    stg_o[k] = (y < a.H && x < a.W) ? (unsigned)(((y * a.W + x0) * COUTP) * (int)sizeof(T) + g) : 0x80000000u;
+  }
   SSTAMP(9);       // (prologue) weight loads issued, fragment / store geometry
   float mk[NBX];
 #pragma unroll
@@ -395,16 +431,30 @@ conv_stream_kernel(StreamArgs a) {
         u[pc].x = pack2<T>(w4[0], w4[1]);
         u[pc].y = pack2<T>(w4[2], w4[3]);
       }
-      // (Round 4 tried 16-byte stores for the 32-channel tiles -- a half-wave exchange, v_permlane32_swap, pairs the 8-byte runs of
-      // lanes n and n + 32: 2 stores per row instead of 4, ec3 forward 0.302 -> 0.268 ms -- and took it out again: about one launch
-      // in a hundred wrote wrong rows, with the builtin and with the exchange in an asm block padded by idle cycles on both sides
-      // alike; the 8-byte form has never shown it.  DESIGN 4.)
+      if (!staged) {
 #pragma unroll
-      for (int pc = 0; pc < ACCR / 4; ++pc) {
-        if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(u[pc]));
-        else __builtin_amdgcn_raw_buffer_store_b64(u[pc], rd, lofs[b][pc], soff, 0);
+        for (int pc = 0; pc < ACCR / 4; ++pc) {
+          if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(u[pc]));
+          else __builtin_amdgcn_raw_buffer_store_b64(u[pc], rd, lofs[b][pc], soff, 0);
+        }
+      } else {
+#pragma unroll
+        for (int pc = 0; pc < ACCR / 4; ++pc)
+          *reinterpret_cast<u32x2s*>(smem + stg_w[b][pc]) = u[pc];
       }
       SSTAMP(7);     // packing + store issue
+    }
+    if (staged) {
+      // (LDS instructions of one wave execute in order: the reads below see the writes above, and the next step's writes come
+      // after these reads.  The compiler is told so: the two views of the buffer have different vector types)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < NSTG; ++k) {
+        const u32x2s qv = *reinterpret_cast<const u32x2s*>(smem + stg_r[k]);
+        if constexpr (SEUNET_STREAM_PROBE == 2) asm volatile("" :: "v"(qv));
+        else __builtin_amdgcn_raw_buffer_store_b64(qv, rd, stg_o[k], soff, 0);
+      }
+      asm volatile("" ::: "memory");
     }
   };
 
@@ -625,6 +675,8 @@ int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const voi
   a.src = src; a.wpack = wpack; a.bias = bias; a.dst = dst; a.dstC = dst_c; a.dacc = dst_accumulate; a.cout = dst_c;
   a.stats = stats; a.zero = device_zero_page();
   a.debug = g_conv_debug;
+  static const bool no_stage = std::getenv("SEUNET_STREAM_NO_STAGE") != nullptr;     // (diagnostic switch for A/B timing)
+  a.stage = no_stage ? 0 : 1;
   SEUNET_CHECK(a.zero != nullptr, "conv_stream: no zero page on this device");
   a.N = d.N; a.D = d.D; a.H = d.H; a.W = d.W;
   const int planes = cdiv(d.D, dil);
