@@ -55,8 +55,10 @@ for key, (f, w) in table.items():
 def march_is(name, sig):
     n = name.replace(" ", "")
     # (rocprofv3 prints some instantiations demangled with the first integer argument swallowed: "<bool _Accum, int, E, 4, 8, 1, 1>")
-    return "conv_march_kernel" in n and (",".join(map(str, sig)) + ">" in n or "".join("Li%dE" % v for v in sig) in n or
-                                         ("E," + ",".join(map(str, sig[1:])) + ">" in n and len(sig) == 5))
+    # (round 4: a trailing `bool BUF` template argument -- ",true>" / "Lb1E" -- follows MODE)
+    tails = (">", ",true>", ",false>")
+    return "conv_march_kernel" in n and (any(",".join(map(str, sig)) + t in n for t in tails) or "".join("Li%dE" % v for v in sig) in n or
+                                         (len(sig) == 5 and any("E," + ",".join(map(str, sig[1:])) + t in n for t in tails)))
 def last_of_each_step(v):
     v = sorted(v)
     per = max(len(v) // STEPS, 1)
