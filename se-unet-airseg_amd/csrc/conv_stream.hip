@@ -8,13 +8,16 @@
 //   * input-stationary in z: step s stages ONE input plane and adds its contribution to the three output planes s-1, s,
 //     s+1 (accumulators of three planes live in registers, roles rotate with a 3x unrolled loop), so every LDS fragment
 //     read feeds 3 (dz) MFMAs instead of one, and the finished plane s-1 is stored while the march goes on; 8 waves, one
-//     output row each, two per SIMD, so that one wave's fragment waits / stores / DMA issue hide behind the other's MFMAs;
-//   * the planes arrive by LDS-DMA (global_load_lds_dwordx4, inline asm so that hipcc neither counts nor drains them) into a
-//     4-slot ring two steps ahead of their use: counted s_waitcnt vmcnt(N) + one raw s_barrier per step, the HBM latency
-//     of a plane is hidden behind two steps of MFMAs; padding voxels read a zero page;
+//     output row each, two per SIMD.  (Round 4, measured: every variant but the 8-channel one needs > 128 registers per lane,
+//     so ONE workgroup is resident per CU and its two waves per SIMD run in phase -- the barrier lines them up -- and hide
+//     nothing of each other; hence marches as long as the volume allows, see stream_zsteps, and DESIGN 4 for the timeline);
+//   * the planes arrive by LDS-DMA (buffer_load_dwordx4 ... lds through one descriptor per sample, inline asm so that hipcc
+//     neither counts nor drains them; padding lanes and planes outside the march read as zeros) into a ring two or three
+//     steps ahead of their use: counted s_waitcnt vmcnt(N) + one raw s_barrier per step;
 //   * weights live in registers for the whole march (27 taps x 16 B per lane), no weight LDS, no K-chunk loop;
-//   * InstanceNorm partial sums are carried per lane across the march (shifted by the lane's first value, f32) and reduced
-//     once per workgroup (f64), not once per 512-voxel tile.
+//   * InstanceNorm partial sums are carried per lane across the march (f32) and reduced once per workgroup (f64), not once
+//     per 512-voxel tile;
+//   * finished rows of the 32-channel tiles leave through a wave-private LDS row buffer as contiguous stores (round 4).
 // MFMA shapes by channel counts (weights = A operand, so a lane owns one voxel and runs of 4 consecutive channels):
 //   CIN 16 -> COUT <= 32 : v_mfma_f32_32x32x16 (K = the 16 channels of one tap)                       ec3 fwd, dc6 dgrad, ec2 dgrad
 //   CIN 32 -> COUT <= 16 : v_mfma_f32_16x16x32 (K = the 32 channels of one tap)                       dc6 fwd, ec3 dgrad
