@@ -561,14 +561,16 @@ conv_stream_kernel(StreamArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 struct StreamPackArgs { const float* w; void* out; int cin_w, cout_w, tflip, cin_e, cout_e, coutp, xfold, np; };
 
+static constexpr int ST_PACK_MAX = 8;          // layers per multi-layer launch (the network has four forward and three data-gradient ones)
+struct StreamPackList { StreamPackArgs j[ST_PACK_MAX]; int n; };
+
+// blockIdx.x = packed tap index k; one wave writes the 64 fragments of that tap
 template <typename T>
-__global__ void __launch_bounds__(64)
-conv_stream_pack_kernel(StreamPackArgs p) {
-  // blockIdx.x = packed tap index; one wave writes the 64 fragments of that tap
+__device__ __forceinline__ void conv_stream_pack_body(const StreamPackArgs& p, int k) {
   const int lane = threadIdx.x;
   const int vpk = p.xfold ? 4 / p.np : 1;       // x-tap slots per MFMA
   const int ndx = p.xfold ? (3 + vpk - 1) / vpk : 3;
-  const int k = blockIdx.x;                   // ((dz*3 + dy) * ndx + dxi)
+  if (k >= 9 * ndx) return;                   // ((dz*3 + dy) * ndx + dxi)
   const int dxi = k % ndx, zy = k / ndx;
   const int row = p.coutp == 32 ? (lane & 31) : (lane & 15);     // output channel
   const int grp = p.coutp == 32 ? (lane >> 5) : (lane >> 4);     // k-group: 8 elements
@@ -586,6 +588,13 @@ conv_stream_pack_kernel(StreamPackArgs p) {
     out[j] = from_f32<T>(v);
   }
 }
+template <typename T>
+__global__ void __launch_bounds__(64)
+conv_stream_pack_kernel(StreamPackArgs p) { conv_stream_pack_body<T>(p, blockIdx.x); }
+// every streaming layer of a pass in one launch: blockIdx.y = layer
+template <typename T>
+__global__ void __launch_bounds__(64)
+conv_stream_pack_multi_kernel(StreamPackList l) { conv_stream_pack_body<T>(l.j[blockIdx.y], blockIdx.x); }
 
 // which variant serves (padded source channels, destination channels); 0 = none
 static int stream_variant(int dtype, int taps, int dil, int src_c, int dst_c) {
@@ -625,15 +634,35 @@ int conv_stream_slots(Dims d, int dil) {
   return cdiv(d.H, ST_TY) * cdiv(d.W, ST_TX) * cdiv(planes, zs) * dil;
 }
 
-int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int src_c, int dst_c, void* wpack, hipStream_t s) {
+static int stream_pack_args(int dtype, const float* w, int cin_w, int cout_w, int tflip, int src_c, int dst_c, void* wpack, StreamPackArgs& p) {
   const int cin_e = tflip ? cout_w : cin_w, cout_e = tflip ? cin_w : cout_w;
   const int var = stream_variant(dtype, 27, 1, src_c, dst_c);
   SEUNET_CHECK(var != 0 && w && wpack, "conv_stream_pack: unsupported shape (%d -> %d channels)", src_c, dst_c);
   SEUNET_CHECK(cin_e <= src_c && cout_e <= dst_c, "conv_stream_pack: weight (%d -> %d) exceeds the tensors (%d -> %d)", cin_e, cout_e, src_c, dst_c);
-  StreamPackArgs p{w, wpack, cin_w, cout_w, tflip, cin_e, cout_e, var == 1 ? 32 : 16, (var == 3 || var == 4) ? 1 : 0, src_c / 8};
-  if (dtype == SEUNET_F16) conv_stream_pack_kernel<f16_t><<<var == 3 ? 9 : (var == 4 ? 18 : 27), 64, 0, s>>>(p);
-  else conv_stream_pack_kernel<bf16_t><<<var == 3 ? 9 : (var == 4 ? 18 : 27), 64, 0, s>>>(p);
+  p = StreamPackArgs{w, wpack, cin_w, cout_w, tflip, cin_e, cout_e, var == 1 ? 32 : 16, (var == 3 || var == 4) ? 1 : 0, src_c / 8};
+  return 0;
+}
+int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int src_c, int dst_c, void* wpack, hipStream_t s) {
+  StreamPackArgs p{};
+  if (int e = stream_pack_args(dtype, w, cin_w, cout_w, tflip, src_c, dst_c, wpack, p)) return e;
+  if (dtype == SEUNET_F16) conv_stream_pack_kernel<f16_t><<<27, 64, 0, s>>>(p);
+  else conv_stream_pack_kernel<bf16_t><<<27, 64, 0, s>>>(p);
   SEUNET_LAUNCH_CHECK();
+  return 0;
+}
+// all streaming layers of a pass in one launch (the weights change every step; seven 6-us launches per step otherwise)
+int launch_conv_stream_pack_multi(int dtype, const StreamPackJob* jobs, int n, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += ST_PACK_MAX) {
+    StreamPackList l{};
+    l.n = n - i0 < ST_PACK_MAX ? n - i0 : ST_PACK_MAX;
+    for (int i = 0; i < l.n; ++i) {
+      const StreamPackJob& j = jobs[i0 + i];
+      if (int e = stream_pack_args(dtype, j.w, j.cin_w, j.cout_w, j.tflip, j.src_c, j.dst_c, j.wpack, l.j[i])) return e;
+    }
+    if (dtype == SEUNET_F16) conv_stream_pack_multi_kernel<f16_t><<<dim3(27, l.n), 64, 0, s>>>(l);
+    else conv_stream_pack_multi_kernel<bf16_t><<<dim3(27, l.n), 64, 0, s>>>(l);
+    SEUNET_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -406,6 +406,7 @@ struct Exec {
     mark("pack_w");
     std::vector<ConvPackJob> jobs;
     std::vector<MarchPackJob> mjobs;
+    std::vector<StreamPackJob> sjobs;
     for (int i = 0; i < kNumOps; ++i) {
       const OpDesc& o = kOps[i];
       if (o.kind != OP_GATED && o.kind != OP_CAT) continue;
@@ -414,8 +415,7 @@ struct Exec {
       if ((!dgrad && r.stream_f) || (dgrad && r.stream_d)) {
         // PyTorch weight (cout, cin, 3,3,3); the data gradient reads it transposed / mirrored
         const int src_c = dgrad ? r.cout : p.C[o.src[0]], dst_c = dgrad ? p.C[o.src[0]] : r.cout;
-        if (int e = launch_conv_stream_pack(p.d.dtype, P(n + ".conv1.weight"), r.cin, r.cout, dgrad ? 1 : 0, src_c, dst_c,
-                                            at(dgrad ? r.wp_d : r.wp_f), s)) return e;
+        sjobs.push_back({P(n + ".conv1.weight"), at(dgrad ? r.wp_d : r.wp_f), r.cin, r.cout, dgrad ? 1 : 0, src_c, dst_c});
         continue;
       }
       if ((!dgrad && r.march_f) || (dgrad && r.march_d)) {
@@ -432,6 +432,8 @@ struct Exec {
         jobs.push_back({P(n + ".conv1.weight"), at(r.wp_d), r.taps, r.cin, r.cout, 1});
       }
     }
+    if (!sjobs.empty())
+      if (int e = launch_conv_stream_pack_multi(p.d.dtype, sjobs.data(), (int)sjobs.size(), s)) return e;
     if (!mjobs.empty())
       if (int e = launch_conv_march_pack_multi(p.d.dtype, mjobs.data(), (int)mjobs.size(), s)) return e;
     return launch_conv_pack_weights_multi(p.d.dtype, jobs.data(), (int)jobs.size(), s);

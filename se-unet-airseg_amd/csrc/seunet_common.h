@@ -282,6 +282,8 @@ bool conv_stream_supported(int dtype, int taps, int dil, int src_c, int dst_c);
 size_t conv_stream_wpack_bytes(int src_c);
 int conv_stream_slots(Dims d, int dil);
 int launch_conv_stream_pack(int dtype, const float* w, int cin_w, int cout_w, int tflip, int src_c, int dst_c, void* wpack, hipStream_t s);
+struct StreamPackJob { const float* w; void* wpack; int cin_w, cout_w, tflip, src_c, dst_c; };
+int launch_conv_stream_pack_multi(int dtype, const StreamPackJob* jobs, int n, hipStream_t s);
 int launch_conv_stream(int dtype, int dil, const void* src, int src_c, const void* wpack, const float* bias, void* dst, int dst_c,
                        int dst_accumulate, double* stats, Dims d, hipStream_t s);
 
