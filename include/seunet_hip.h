@@ -13,7 +13,8 @@
  *           a kernel that pads through it runs on that device -- or up front by seunet_init);
  *       (2) per kernel instantiation, a bit mask of the devices on which hipFuncSetAttribute (LDS above 64 KB) has run;
  *       (3) the opt-in seunet_prof_* recorder (process-wide, off by default; the per-launch-group timer of bench.py);
- *       (4) the diagnostic environment switches SEUNET_NO_STREAM / SEUNET_UP_TILED, read when a plan is built.
+ *       (4) diagnostic environment switches (SEUNET_NO_STREAM, SEUNET_NO_MARCH, SEUNET_STREAM_WGS, ...: INTEGRATION.md section 2),
+ *           read once per process, for A/B timing only.
  *     Apart from these everything is parameterised by (pointers, stream) and calls are re-entrant across threads and
  *     streams; a graph object (seunet_net_forward_capture) is owned by the caller like any other handle;
  *   - activations inside the library are channels-last [N][D][H][W][C], C a multiple of 8, f32, bf16 or
