@@ -498,6 +498,22 @@ def test_conv_stream_forward_and_stats(S, case, shape):
     assert float((S.from_cl(raw2, cout) - got).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("case", [(16, 16, 32, 2), (32, 32, 16, 1), (8, 8, 16, 1)])
+def test_conv_stream_result_of_a_sample_does_not_depend_on_its_batch(S, case):
+    """The z axis is cut into marches by the SAMPLE's extents only (csrc/conv_stream.hip stream_zsteps), so a sample's raw output
+    and its InstanceNorm partial records are the same bits alone and inside a batch of three -- what the data-parallel
+    equivalence tests and the window loop build on.  72 planes: more than one march at dilation 1."""
+    src_c, cin, cout, dil = case
+    x = rnd("bf16", gen(3, src_c, 72, 16, 64, seed=12))
+    wt = rnd("bf16", gen(cout, cin, 3, 3, 3, seed=13, scale=(27 * cin) ** -0.5))
+    b = gen(cout, seed=14, scale=0.1)
+    raw3, part3, slots3 = S.conv3d_stream(S.to_cl(x.cuda(), "bf16"), wt.cuda(), b.cuda(), dil, want_stats=True)
+    raw1, part1, slots1 = S.conv3d_stream(S.to_cl(x[1:2].cuda(), "bf16"), wt.cuda(), b.cuda(), dil, want_stats=True)
+    assert slots1 == slots3
+    assert torch.equal(raw3[1:2], raw1)
+    assert torch.equal(part3[1:2], part1)
+
+
 @pytest.mark.parametrize("acc", [False, True])
 @pytest.mark.parametrize("case", [(16, 8, 8, 1), (32, 16, 16, 2), (16, 32, 32, 1), (16, 8, 16, 1)])   # (dy channels, dx channels, dx tensor channels, dil)
 def test_conv_stream_data_gradient(S, case, acc):
