@@ -296,12 +296,12 @@ conv_stream_kernel(StreamArgs a) {
   // wave-private LDS buffer instead: 8-byte writes in the tile's layout (16-byte slots XOR-swizzled by the voxel number, so that
   // every bank pair takes 4 lanes), 8-byte reads in memory order, four stores of 512 contiguous bytes.  ec3 forward 0.299 ->
   // 0.255 ms, dc6 data gradient 0.32 -> 0.294.  (The 16-channel tiles keep the direct form: their records are 32 bytes, one
-  // instruction already covers 512 dense bytes, and staging cost them 10 %.  16-byte stores -- two per row -- would halve the
-  // instruction count again, and BOTH ways of forming them wrote wrong rows in about one launch of a hundred: from registers after a
-  // v_permlane32_swap exchange, and from this LDS buffer with ds_read_b128; the 8-byte form of the same staging never has.  It is
-  // buffer_store_dwordx4 next to the LDS-DMA traffic of this kernel that misbehaves, not the exchange; not understood.)
+  // instruction already covers 512 dense bytes, and staging cost them 10 %.  16-byte stores -- two per row -- were tried from
+  // registers after a v_permlane32_swap exchange and from this buffer with ds_read_b128; both wrote wrong rows now and then, which
+  // turned out to be the counted wait of the march, not the stores: see there.  With the wait fixed they are correct and no faster
+  // than the four 8-byte stores, which stay.)
   const bool staged = COUTP == 32 && a.stage != 0 && a.dstC == COUTP && a.cout == COUTP;         // wave-uniform
-  constexpr int NSTG = COUTP == 32 ? 4 : 2;          // 8-byte pieces per lane of the row image (16-byte stores: see finish())
+  constexpr int NSTG = COUTP == 32 ? 4 : 2, SPB = 8; // 8-byte pieces per lane of the row image
   const unsigned stg_base = (unsigned)(Geo::STAGE + wave * Geo::STG);
   unsigned stg_w[NBX][ACCR / 4];      // LDS byte address of the lane's 8-byte pieces
   unsigned stg_r[NSTG];               // LDS byte address of the lane's 16 bytes of the row image
@@ -316,7 +316,7 @@ conv_stream_kernel(StreamArgs a) {
     }
 #pragma unroll
   for (int k = 0; k < NSTG; ++k) {
-    const int g = k * 512 + lane * 8;                             // byte of the row image
+    const int g = k * 64 * SPB + lane * SPB;                      // byte of the row image
     const int v = g / (COUTP * 2);
     if constexpr (COUTP == 32) stg_r[k] = stg_base + (unsigned)(v * 64 + 16 * (((g >> 4) & 3) ^ ((v >> 1) & 3)) + (g & 8));
     else stg_r[k] = stg_base + (unsigned)g;
@@ -463,13 +463,15 @@ conv_stream_kernel(StreamArgs a) {
 
   // ---- the march ----
   // VMEM issue order of a wave: [prologue: DMA(0) .. DMA(PF-1)]  then per step s: DMA(s+PF) (inside compute), stores(s).
-  // At the top of step s >= 1 plane s must have landed; it was issued in step s - PF (or the prologue), and younger than it are
-  // DMA(s+1) .. DMA(s+PF-1) and the stores of min(s, PF) steps: waiting for all but (PF-1) * LW + min(s, PF) * (stores per step)
-  // operations is exactly sufficient (the first trip of the loop, s < 3, uses the count of s = 1; round 3 used that count for every
-  // step, which also waited for the NEXT plane and for the stores of two steps ago).  Then one barrier: every wave's part of the
-  // plane is in LDS, and every wave has finished reading the slot that this step's prefetch overwrites (ring = PF + 2 slots).
+  // At the top of step s >= 1 plane s must have landed; it was issued in step s - PF (or the prologue), and the only LOADS
+  // younger than it are DMA(s+1) .. DMA(s+PF-1): the wait allows (PF-1) * LW outstanding operations and counts NO store as
+  // outstanding.  Round 3 (and this round at first) added the stores issued since -- correct if operations retire in issue
+  // order, and they do not: with 16-byte stores about one launch in a hundred passed the wait before its plane had landed
+  // (wrong output rows, never reproducibly), because a store can retire ahead of an older LDS-DMA load and lower the count
+  // early.  The 8-byte stores never showed it in thousands of runs; the count no longer relies on it (same speed: the stores
+  // of the previous step are acknowledged within the step).  Then one barrier: every wave's part of the plane is in LDS, and
+  // every wave has finished reading the slot that this step's prefetch overwrites (ring = PF + 2 slots).
   constexpr int LW = ITEMS + (DACC ? Geo::OLDI : 0);   // DMA instructions per wave and step (padded to the same count in every wave)
-  constexpr int MINST = Geo::STORES;                    // store instructions per wave and step
 #pragma unroll
   for (int k = 0; k < Geo::PF; ++k) { dma_plane(k, k); dma_old(k, k); }
   // The weight loads are ordinary (compiler-visible) loads, and the compiler waits for a load at its first use -- which is inside
@@ -490,12 +492,7 @@ conv_stream_kernel(StreamArgs a) {
         const int s = s0 + PH;
         if (s < nsteps) {
           if (s > 0) {
-#ifdef SEUNET_STREAM_OLDWAIT
-            if (true) stream_wait_vm<(Geo::PF - 1) * LW + MINST>();
-#else
-            if (s0 == 0) stream_wait_vm<(Geo::PF - 1) * LW + MINST>();
-#endif
-            else stream_wait_vm<(Geo::PF - 1) * LW + Geo::PF * MINST>();
+            stream_wait_vm<(Geo::PF - 1) * LW>();
             SSTAMP(1);   // counted wait for the plane (and the stores of two steps ago)
             __builtin_amdgcn_s_barrier();
             SSTAMP(2);   // barrier
