@@ -466,10 +466,13 @@ conv_march_kernel(MarchArgs a) {
   // ---- the march ----
   // Vector-memory operations of a wave, in program order: [prologue: DMA(0), DMA(1)], then per step s exactly TOT of them:
   // old rows (MODE 2, first), ITEMS plane instructions for plane s + 2, STORES stores.  At the top of step s >= 1 plane s
-  // (issued in step s - 2, or in the prologue) must have landed: at most the TOT operations of step s - 1 may be
-  // outstanding; with accumulation the old rows of step s (issued first in step s - 1) must have landed too: at most
-  // TOT - OLDN.  Then one barrier: every wave's part of the plane is in the LDS, and every wave has finished reading the
-  // slot (plane s - 1) that this step's prefetch overwrites.
+  // (issued in step s - 2, or in the prologue) must have landed, with accumulation the old rows of step s (issued first in
+  // step s - 1) too: the only LOADS younger than those are the ITEMS plane instructions of step s - 1, so the wait allows
+  // ITEMS outstanding operations and counts NO store as outstanding (round 4: until then it allowed TOT - OLDN, i.e. also the
+  // stores of step s - 1 -- right only if stores and LDS-DMA loads retire in issue order, and they need not: the streaming conv's
+  // 16-byte-store experiments passed such a wait before their plane had landed, DESIGN 4.  Same speed here).  Then one barrier:
+  // every wave's part of the plane is in the LDS, and every wave has finished reading the slot (plane s - 1) that this step's
+  // prefetch overwrites.
   static_for<MA_PF>([&](auto k_c) __attribute__((always_inline)) {
     constexpr int k = decltype(k_c)::value;
     const PlaneRef r = plane_of(k, k);
@@ -490,7 +493,7 @@ conv_march_kernel(MarchArgs a) {
       constexpr int PH = decltype(ph_c)::value;
       const int s = 3 * rd3 + PH;
       if (PH > 0 || rd3 > 0) {
-        march_wait_vm<Geo::TOT - Geo::OLDN>();
+        march_wait_vm<ITEMS>();
         __builtin_amdgcn_s_barrier();
       }
       compute(s, slot, slot_pf, ph_c);
